@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the hot path on MI355X.
+
+One "step" = one full render of the workload (BASELINE.json configs[2], the configuration the metric is quoted on:
+the ~485-sphere bouncing-balls scene, 1920x1080, 64 spp, depth 50) with the scene already resident in HBM.
+N GPUs (one process per GPU, torchrun): the frame is sharded in interleaved 8-row strips, every rank renders its
+band into HBM, the bands are gathered with RCCL (torch.distributed backend "nccl") and scattered into frame order
+by kernel K4.  Strong scaling: the frame is fixed, value = ray segments of the whole frame / time.
+
+Prints ONE JSON line on rank 0 (see the task contract); extra keys: roofline, cpu_baseline, diagnostics.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)": 256 CU x 4 SIMD x 32 lanes x 2 x 2.4 GHz
+
+
+def build_workload(name, width, spp, depth):
+    from raytracer_amd import presets
+
+    if name == "balls1080p":
+        return presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(width, spp, depth), "bouncing_balls(seed=1)"
+    if name == "mars":
+        return presets.mars_texture_scene(), presets.default_camera(width, spp, depth), "mars_texture_scene"
+    if name == "textured":
+        return presets.textured_scene(), presets.textured_camera(width, spp, depth), "textured_scene"
+    if name.startswith("stress"):
+        n = int(name[6:] or 10000)
+        return presets.stress_scene(n, 1), presets.stress_camera(width, spp, depth), f"stress({n})"
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(scene, cam, seed, seconds_budget=12.0):
+    """The restated reference (oracle, f64, faithful BVH walk) timed on this box's host cores on a bounded sample:
+    a band of rows from the middle of the same frame, sized from a 1-row probe to about `seconds_budget` seconds."""
+    from oracle import binding as ob
+    from raytracer_amd import abi
+
+    H = cam.height
+    mid = H // 2
+    t0 = time.perf_counter()
+    _, _, seg, _ = ob.render(scene.flat, cam.pod, abi.F64, seed=seed, use_bvh=True, threads=1, rows=(mid, mid + 1), want_rgb8=False)
+    probe = time.perf_counter() - t0
+    rows = max(1, min(H - mid, int(seconds_budget / max(probe, 1e-3))))
+    t0 = time.perf_counter()
+    _, _, seg, _ = ob.render(scene.flat, cam.pod, abi.F64, seed=seed, use_bvh=True, threads=1, rows=(mid, mid + rows), want_rgb8=False)
+    dt1 = time.perf_counter() - t0
+    single = seg / dt1 / 1e6
+    threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU is 16 cores
+    rows_mt = max(threads, min(H - mid, rows * threads // 2))
+    t0 = time.perf_counter()
+    _, _, seg_mt, _ = ob.render(scene.flat, cam.pod, abi.F64, seed=seed, use_bvh=True, threads=threads, rows=(mid, mid + rows_mt), want_rgb8=False)
+    dtn = time.perf_counter() - t0
+    base = {
+        "value": round(single, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+        "sample": f"rows {mid}..{mid + rows} of the same {cam.width}x{H}x{cam.pod.samples_per_pixel}spp frame, f64 oracle with the reference's BVH walk, "
+                  f"{seg} segments in {dt1:.1f} s, single thread (the reference is single-threaded)",
+    }
+    mt = {
+        "value": round(seg_mt / dtn / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"rows {mid}..{mid + rows_mt}, row-parallel, {seg_mt} segments in {dtn:.1f} s",
+    }
+    return base, mt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="balls1080p")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--precision", type=int, default=32, choices=[32, 64])
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+
+    from raytracer_amd import abi, dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    td = None
+    if world > 1:
+        import torch.distributed as td
+
+        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    lib = abi.load()
+    scene, cam, scene_name = build_workload(args.workload, args.width, args.spp, args.depth)
+    ds = scene.device_scene(local_rank)
+    H, W, S = cam.height, cam.width, dist.DEFAULT_STRIP_ROWS
+    real = torch.float32 if args.precision == 32 else torch.float64
+    rows0 = dist.part_rows(H, S, 0, world)
+    band = torch.zeros((rows0, W, 3), dtype=real, device="cuda")
+    band8 = torch.zeros((rows0, W, 3), dtype=torch.uint8, device="cuda")
+    frame = torch.zeros((H, W, 3), dtype=real, device="cuda") if rank == 0 else None
+    opts = cam.opts(precision=args.precision, seed=args.seed, strip_rows=S, part_index=rank, part_count=world, flags=abi.FLAG_COMPACT_ROWS)
+    stream = torch.cuda.current_stream().cuda_stream
+    elem = 3 * (4 if args.precision == 32 else 8)
+
+    def step():
+        st = abi.MirtStats()
+        abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(opts), band.data_ptr(), band8.data_ptr(), stream, C.byref(st)))
+        if world > 1:
+            allb = dist.gather_bands(band, world)  # RCCL all-gather over xGMI: the one exchange step
+            if rank == 0:
+                abi.check(lib.mirt_deinterleave_device(allb.data_ptr(), band.numel() * band.element_size(), world, S, W, H, elem, frame.data_ptr(), stream))
+        else:
+            abi.check(lib.mirt_deinterleave_device(band.data_ptr(), band.numel() * band.element_size(), 1, S, W, H, elem, frame.data_ptr(), stream))
+        return st
+
+    def fence():
+        if td is not None:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(args.steps)]
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    seg = sum(s.segments for s in stats)
+    flops = sum(18 * s.static_tests + 27 * s.moving_tests + 5 * s.segments for s in stats)
+    kern_ms = sum(s.kernel_ms for s in stats)
+    iters = sum(s.wave_iterations for s in stats)
+    narrow = sum(s.narrow_tests for s in stats)
+    if td is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+        v = torch.tensor([seg, flops, iters, narrow], dtype=torch.float64, device="cuda")
+        td.all_reduce(v, op=td.ReduceOp.SUM)
+        seg_all, flops_all, iters_all, narrow_all = (float(x) for x in v.tolist())
+    else:
+        seg_all, flops_all, iters_all, narrow_all = float(seg), float(flops), float(iters), float(narrow)
+
+    if rank == 0:
+        achieved = (flops / (kern_ms * 1e-3)) / 1e12 if kern_ms > 0 else 0.0  # rank 0's kernel: per-GPU rate
+        out = {
+            "metric": "Mrays/s at 1080p (ray segment = one closest-hit query) + % of FP32 VALU peak",
+            "value": round(seg_all / elapsed / 1e6, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == 32 else "f64",
+            "data": "synthetic (seeded restatement of the reference's bouncing_balls_scene; reference textures pre-decoded)",
+            "config": {
+                "workload": f"{scene_name}: {scene.flat.n_spheres} spheres, {W}x{H}, {cam.pod.samples_per_pixel} spp, depth {cam.pod.max_bounce_depth}",
+                "parallelism": f"interleaved {S}-row strips over {world} GPU(s), RCCL all-gather of f32 RGB bands",
+                "seed": args.seed,
+            },
+            "roofline": {
+                "bound": "valu_fp32",
+                "achieved": round(achieved, 3),
+                "peak": FP32_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "kernel": "render_kernel<float>" if args.precision == 32 else "render_kernel<double>",
+                "kernel_ms_avg": round(kern_ms / max(1, len(stats)), 3),
+                "flops_per_segment": round(flops / max(seg, 1), 1),
+                "note": "algorithmic flops = 18/static sphere test + 27/moving sphere test + 5/segment (SURVEY.md 8d); rank 0's launches",
+            },
+            "diagnostics": {
+                "segments_per_step": seg_all / args.steps,
+                "lane_utilisation": round(seg_all / max(iters_all * 64.0, 1.0), 4),
+                "narrow_tests_per_segment": round(narrow_all / max(seg_all, 1.0), 3),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, mt = cpu_baseline(scene, cam, args.seed, args.cpu_seconds)
+            out["cpu_baseline"] = base
+            out["cpu_baseline_all_cores"] = mt
+        print(json.dumps(out), flush=True)
+    if td is not None:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,202 @@
+/*
+ * mirt.h — C ABI of the MI355X (gfx950) render backend for the sphere path tracer.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own; the seam this
+ * library replaces is the Rust call pair
+ *     Camera::build(..)            reference src/camera/camera.rs:123-206   (stays on the host side)
+ *     Camera::render(&self,&Scene) reference src/camera/camera.rs:232-259   (replaced by mirt_render)
+ * plus the scene container `Scene::{add,build_bvh,hit}` (src/scene/hittable.rs:72-99), which is
+ * flattened into a mirt_scene_desc when `build_bvh`/`render` is called.
+ *
+ * Conventions: every entry point returns 0 (MIRT_OK) or a negative mirt_status; nothing aborts or
+ * unwinds across the ABI; output buffers are caller-owned; mirt_last_error() is thread-local.
+ * Plain pointers and sizes only - no C++/torch types.
+ */
+#ifndef MIRT_H
+#define MIRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRT_ABI_VERSION 1u
+#define MIRT_MISS_ID 0xFFFFFFFFu /* hit-id of a ray that hits nothing (SURVEY.md §8c "Hit id definition") */
+
+typedef enum mirt_status {
+    MIRT_OK = 0,
+    MIRT_ERR_INVALID = -1,   /* bad argument / malformed scene description                         */
+    MIRT_ERR_NO_DEVICE = -2, /* no HIP device, or device index out of range                        */
+    MIRT_ERR_HIP = -3,       /* a HIP runtime call failed (text in mirt_last_error)                */
+    MIRT_ERR_NAN = -4,       /* a NaN reached the quantiser: the reference panics here             */
+                             /* (src/core/rgb.rs:33 `expect("f64 is nan!")`); we return a code     */
+    MIRT_ERR_NOMEM = -5,
+    MIRT_ERR_TOO_LARGE = -6  /* a size exceeds a documented limit                                  */
+} mirt_status;
+
+/* ---- scene description (host memory, copied by mirt_scene_create) --------------------------- */
+
+typedef enum mirt_material_kind {
+    MIRT_MAT_LAMBERTIAN = 0, /* src/scene/material.rs:29-84   */
+    MIRT_MAT_METAL = 1,      /* src/scene/material.rs:86-114  */
+    MIRT_MAT_DIELECTRIC = 2  /* src/scene/material.rs:116-154 */
+} mirt_material_kind;
+
+typedef enum mirt_texture_kind {
+    MIRT_TEX_SOLID = 0,   /* src/scene/texture.rs:14-28 */
+    MIRT_TEX_CHECKER = 1, /* src/scene/texture.rs:30-59 (children are always SolidColor, :37-43) */
+    MIRT_TEX_IMAGE = 2    /* src/scene/texture.rs:61-94 */
+} mirt_texture_kind;
+
+/* RGB8 image, row-major, 3 bytes per texel, as `image::RgbImage` (src/scene/image_loader.rs:5-8). */
+typedef struct mirt_image {
+    uint32_t width;
+    uint32_t height; /* 0 is legal: ImageTexture then returns cyan (texture.rs:78-80) */
+    const uint8_t* rgb;
+} mirt_image;
+
+typedef struct mirt_texture {
+    uint32_t kind;    /* mirt_texture_kind                                              */
+    uint32_t image;   /* IMAGE: index into images[]                                     */
+    double color[3];  /* SOLID: albedo; CHECKER: even colour                            */
+    double odd[3];    /* CHECKER: odd colour                                            */
+    double inv_scale; /* CHECKER: 1/scale, computed by the caller like texture.rs:39    */
+} mirt_texture;
+
+typedef struct mirt_material {
+    uint32_t kind;      /* mirt_material_kind                                                 */
+    uint32_t texture;   /* LAMBERTIAN: index into textures[]                                  */
+    double reflectance; /* LAMBERTIAN: scatter probability and attenuation divisor (:68,:78)  */
+    double albedo[3];   /* METAL                                                              */
+    double fuzz;        /* METAL: used only if has_fuzz                                       */
+    uint32_t has_fuzz;  /* METAL: `fuzz: Option<f64>` is Some (material.rs:88)                */
+    uint32_t _pad;
+    double ior;         /* DIELECTRIC: refraction_index                                       */
+} mirt_material;
+
+/* One sphere = one hit id (its index in spheres[]).  src/scene/sphere.rs:14-24. */
+typedef struct mirt_sphere {
+    double center0[3]; /* Center::Static(p) or Center::Moving(p, _)      */
+    double center1[3]; /* Center::Moving(_, p); ignored unless moving    */
+    double radius;     /* stored as max(r, 0) like sphere.rs:31,50       */
+    uint32_t material; /* index into materials[]                         */
+    uint32_t moving;   /* 0 = static                                     */
+} mirt_sphere;
+
+typedef struct mirt_scene_desc {
+    uint32_t n_spheres;
+    uint32_t n_materials;
+    uint32_t n_textures;
+    uint32_t n_images;
+    const mirt_sphere* spheres;
+    const mirt_material* materials;
+    const mirt_texture* textures;
+    const mirt_image* images;
+} mirt_scene_desc;
+
+/* The POD left behind by Camera::build (struct Camera, src/camera/camera.rs:107-120).  The host
+ * side keeps computing it exactly as camera.rs:135-182 does; the device only consumes it. */
+typedef struct mirt_camera {
+    double lookfrom[3];
+    double px_du[3];
+    double px_dv[3];
+    double vp_upper_left[3];
+    double px00_loc[3];
+    double disk_u_r[3];   /* Defocuser::disk_u_r = u * defocus_radius (camera.rs:84) */
+    double disk_v_r[3];
+    double defocus_angle; /* <= 0 disables the lens sample (camera.rs:220)           */
+    uint32_t img_width;
+    uint32_t img_height;
+    uint32_t samples_per_pixel; /* 0 = anti-aliasing disabled: the deterministic branch camera.rs:247-254 */
+    uint32_t max_bounce_depth;
+} mirt_camera;
+
+typedef enum mirt_precision {
+    MIRT_F64 = 64, /* parity mode: the reference's arithmetic, operation for operation       */
+    MIRT_F32 = 32  /* throughput mode: binary32, fused discriminant (see DESIGN.md "f32 spec") */
+} mirt_precision;
+
+#define MIRT_FLAG_COMPACT_ROWS 1u /* outputs hold only the rows this call owns, packed in row order */
+
+/* Which rows a call renders: rows are grouped in strips of `strip_rows`; strip s is owned when
+ * s % part_count == part_index (interleaved strips).  part_count <= 1 = whole image. */
+typedef struct mirt_opts {
+    uint32_t precision;  /* mirt_precision */
+    uint32_t flags;
+    uint64_t seed;       /* key of the counter-based RNG; the image does not depend on the partition */
+    uint32_t strip_rows; /* 0 -> 8 */
+    uint32_t part_index;
+    uint32_t part_count;
+    uint32_t _pad;
+} mirt_opts;
+
+/* Counters written by a render call (device-side exact counts). */
+typedef struct mirt_stats {
+    uint64_t segments;        /* ray segments traced = closest-hit queries (camera.rs:273)        */
+    uint64_t sphere_tests;    /* static_tests + moving_tests                                      */
+    uint64_t static_tests;
+    uint64_t moving_tests;
+    uint64_t narrow_tests;    /* candidates (d >= 0) that reached the root computation            */
+    uint64_t wave_iterations; /* wave-level passes of the segment loop (64 lanes each)            */
+    uint64_t nan_pixels;      /* pixels whose radiance was NaN (reference would panic)            */
+    double kernel_ms;         /* hipEvent time of the dominant kernel, on the stream it ran on    */
+} mirt_stats;
+
+typedef struct mirt_scene mirt_scene; /* opaque: device-resident flattened scene */
+
+/* ---- entry points ---------------------------------------------------------------------------- */
+
+int mirt_abi_version(void);
+int mirt_device_count(void);
+const char* mirt_last_error(void);
+
+/* Replaces Scene::build_bvh (src/scene/hittable.rs:86-90): freezes the scene into SoA device
+ * buffers on HIP device `device`.  The caller keeps its own buffers. */
+int mirt_scene_create(const mirt_scene_desc* desc, int device, mirt_scene** out);
+void mirt_scene_destroy(mirt_scene* scene);
+
+/* Deterministic primary rays: the no-AA branch of Camera::render (camera.rs:247-254) + Scene::hit
+ * (hittable.rs:92-98) in the interval (0.001, inf).  id[W*H] = sphere index or MIRT_MISS_ID,
+ * t[W*H] = hit parameter as `precision` reals (float or double; +inf on a miss).  Host buffers. */
+int mirt_primary_hits(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
+                      uint32_t* id, void* t);
+
+/* Replaces the body of Camera::render (camera.rs:237-257) + ARgb's Display quantiser
+ * (src/core/rgb.rs:20-36).  rgb_linear: W*H*3 reals (pixel-interleaved r,g,b), rgb8: W*H*3 bytes
+ * ready for the "r g b\n" PPM lines; either may be NULL.  Host buffers.  stats may be NULL. */
+int mirt_render(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
+                void* rgb_linear, uint8_t* rgb8, mirt_stats* stats);
+
+/* Same as mirt_render / mirt_primary_hits but the outputs are DEVICE pointers on the scene's
+ * device and the work is enqueued on `stream` (a hipStream_t, NULL = default stream).  The calls
+ * synchronise the stream before returning only if `stats` is non-NULL.  Used by the multi-GPU
+ * gather (the band is handed to RCCL without leaving HBM) and by bench.py. */
+int mirt_render_device(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
+                       void* d_rgb_linear, uint8_t* d_rgb8, void* stream, mirt_stats* stats);
+int mirt_primary_hits_device(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
+                             uint32_t* d_id, void* d_t, void* stream);
+
+/* K3 alone: gamma-2 + quantise n reals (device pointers) exactly like rgb.rs:20-36 and
+ * utils/math.rs:13-21.  *nan_count receives how many inputs were NaN (host pointer, may be NULL). */
+int mirt_quantize_device(const void* d_linear, uint32_t precision, size_t n, uint8_t* d_out,
+                         void* stream, uint64_t* nan_count);
+
+/* K4: scatter `part_count` compact bands (as gathered with RCCL, band r at
+ * d_bands + r * band_stride_bytes, each holding that part's rows packed in row order) into the
+ * full frame.  elem_bytes = bytes per pixel (e.g. 12 for f32 RGB, 3 for rgb8). */
+int mirt_deinterleave_device(const void* d_bands, size_t band_stride_bytes, uint32_t part_count,
+                             uint32_t strip_rows, uint32_t width, uint32_t height,
+                             uint32_t elem_bytes, void* d_frame, void* stream);
+
+/* Rows owned by a part (helper for sizing compact buffers). */
+uint32_t mirt_part_rows(uint32_t height, uint32_t strip_rows, uint32_t part_index, uint32_t part_count);
+
+/* Counter-based RNG, exposed for known-answer tests: Philox4x32-10 block.  out[4]. */
+void mirt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRT_H */

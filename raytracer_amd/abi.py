@@ -1,0 +1,165 @@
+"""ctypes mirror of include/mirt.h and loader for the HIP library (libmirt.so).
+
+There is no CPU fallback: if the in-tree library is missing, loading fails loudly with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MISS_ID = 0xFFFFFFFF
+F64, F32 = 64, 32
+FLAG_COMPACT_ROWS = 1
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
+TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
+
+_D3 = C.c_double * 3
+
+
+class MirtImage(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.POINTER(C.c_uint8))]
+
+
+class MirtTexture(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("image", C.c_uint32), ("color", _D3), ("odd", _D3), ("inv_scale", C.c_double)]
+
+
+class MirtMaterial(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32),
+        ("texture", C.c_uint32),
+        ("reflectance", C.c_double),
+        ("albedo", _D3),
+        ("fuzz", C.c_double),
+        ("has_fuzz", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("ior", C.c_double),
+    ]
+
+
+class MirtSphere(C.Structure):
+    _fields_ = [("center0", _D3), ("center1", _D3), ("radius", C.c_double), ("material", C.c_uint32), ("moving", C.c_uint32)]
+
+
+class MirtSceneDesc(C.Structure):
+    _fields_ = [
+        ("n_spheres", C.c_uint32),
+        ("n_materials", C.c_uint32),
+        ("n_textures", C.c_uint32),
+        ("n_images", C.c_uint32),
+        ("spheres", C.POINTER(MirtSphere)),
+        ("materials", C.POINTER(MirtMaterial)),
+        ("textures", C.POINTER(MirtTexture)),
+        ("images", C.POINTER(MirtImage)),
+    ]
+
+
+class MirtCamera(C.Structure):
+    _fields_ = [
+        ("lookfrom", _D3),
+        ("px_du", _D3),
+        ("px_dv", _D3),
+        ("vp_upper_left", _D3),
+        ("px00_loc", _D3),
+        ("disk_u_r", _D3),
+        ("disk_v_r", _D3),
+        ("defocus_angle", C.c_double),
+        ("img_width", C.c_uint32),
+        ("img_height", C.c_uint32),
+        ("samples_per_pixel", C.c_uint32),
+        ("max_bounce_depth", C.c_uint32),
+    ]
+
+
+class MirtOpts(C.Structure):
+    _fields_ = [
+        ("precision", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("seed", C.c_uint64),
+        ("strip_rows", C.c_uint32),
+        ("part_index", C.c_uint32),
+        ("part_count", C.c_uint32),
+        ("_pad", C.c_uint32),
+    ]
+
+
+class MirtStats(C.Structure):
+    _fields_ = [
+        ("segments", C.c_uint64),
+        ("sphere_tests", C.c_uint64),
+        ("static_tests", C.c_uint64),
+        ("moving_tests", C.c_uint64),
+        ("narrow_tests", C.c_uint64),
+        ("wave_iterations", C.c_uint64),
+        ("nan_pixels", C.c_uint64),
+        ("kernel_ms", C.c_double),
+    ]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/mirt.h declares (tests/test_abi.py checks the built library exports them all)
+EXPORTS = [
+    "mirt_abi_version",
+    "mirt_device_count",
+    "mirt_last_error",
+    "mirt_scene_create",
+    "mirt_scene_destroy",
+    "mirt_primary_hits",
+    "mirt_render",
+    "mirt_render_device",
+    "mirt_primary_hits_device",
+    "mirt_quantize_device",
+    "mirt_deinterleave_device",
+    "mirt_part_rows",
+    "mirt_philox4x32_10",
+]
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libmirt.so")
+_lib = None
+
+
+class MirtError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"mirt error {code}: {text}")
+        self.code = code
+
+
+def load():
+    """Load libmirt.so (built in-tree by __graft_entry__.build() / raytracer_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found - the HIP extension is not built. Run `make -C raytracer_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, u64, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
+    P = C.POINTER
+    lib.mirt_abi_version.restype = C.c_int
+    lib.mirt_device_count.restype = C.c_int
+    lib.mirt_last_error.restype = C.c_char_p
+    lib.mirt_scene_create.argtypes = [P(MirtSceneDesc), C.c_int, P(vp)]
+    lib.mirt_scene_destroy.argtypes = [vp]
+    lib.mirt_scene_destroy.restype = None
+    lib.mirt_primary_hits.argtypes = [vp, P(MirtCamera), P(MirtOpts), vp, vp]
+    lib.mirt_render.argtypes = [vp, P(MirtCamera), P(MirtOpts), vp, vp, P(MirtStats)]
+    lib.mirt_render_device.argtypes = [vp, P(MirtCamera), P(MirtOpts), vp, vp, vp, P(MirtStats)]
+    lib.mirt_primary_hits_device.argtypes = [vp, P(MirtCamera), P(MirtOpts), vp, vp, vp]
+    lib.mirt_quantize_device.argtypes = [vp, u32, sz, vp, vp, P(u64)]
+    lib.mirt_deinterleave_device.argtypes = [vp, sz, u32, u32, u32, u32, u32, vp, vp]
+    lib.mirt_part_rows.argtypes = [u32, u32, u32, u32]
+    lib.mirt_part_rows.restype = u32
+    lib.mirt_philox4x32_10.argtypes = [P(u32), P(u32), P(u32)]
+    lib.mirt_philox4x32_10.restype = None
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise MirtError(code, load().mirt_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,389 @@
+/*
+ * mirt_api.hip — the C ABI of include/mirt.h on top of the HIP kernels (mirt_kernels.h).
+ * Host code only flattens, uploads, launches and times; there is no CPU rendering path in here.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mirt_kernels.h"
+
+using namespace mirt;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail(MIRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+/* ---- device-resident scene ---------------------------------------------------------------------- */
+template <class R> struct SceneBuffers {
+    typename Vec4<R>::type *A = nullptr, *B = nullptr;
+    DevMaterial<R>* mats = nullptr;
+    DevTexture<R>* texs = nullptr;
+};
+struct mirt_scene {
+    int device = 0;
+    uint32_t n = 0, n_static = 0;           /* padded counts (multiples of MIRT_GROUP) seen by the kernels */
+    uint32_t true_n = 0, true_static = 0;   /* real sphere counts, for the statistics */
+    SceneBuffers<float> f32;
+    SceneBuffers<double> f64;
+    uint32_t *orig_id = nullptr, *material = nullptr, *texels = nullptr;
+    DevImage* imgs = nullptr;
+    DevStats* stats = nullptr; /* one per scene: calls on one scene handle are not re-entrant */
+    std::vector<void*> allocs;
+};
+
+template <class T> static int upload(mirt_scene* s, const std::vector<T>& host, T** dev) {
+    size_t bytes = std::max<size_t>(host.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void**)dev, bytes));
+    s->allocs.push_back(*dev);
+    if (!host.empty()) HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MIRT_OK;
+}
+
+template <class R>
+static int upload_real(mirt_scene* s, const mirt_scene_desc* d, const std::vector<uint32_t>& order, SceneBuffers<R>& out) {
+    typedef typename Vec4<R>::type R4;
+    std::vector<R4> A(order.size()), B(order.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+        if (order[k] == 0xFFFFFFFFu) { /* padding record: r*r = -inf makes the discriminant -inf or NaN, never >= 0 */
+            A[k].x = A[k].y = A[k].z = (R)0.0; A[k].w = -(R)INFINITY;
+            B[k].x = B[k].y = B[k].z = (R)0.0; B[k].w = (R)1.0;
+            continue;
+        }
+        const mirt_sphere& sp = d->spheres[order[k]];
+        R c0[3] = {(R)sp.center0[0], (R)sp.center0[1], (R)sp.center0[2]};
+        R c1[3] = {(R)sp.center1[0], (R)sp.center1[1], (R)sp.center1[2]};
+        R r = (R)sp.radius;
+        r = r > (R)0.0 ? r : (R)0.0; /* f64::max(r, 0.0), sphere.rs:31,50 */
+        A[k].x = c0[0]; A[k].y = c0[1]; A[k].z = c0[2]; A[k].w = r * r;
+        if (sp.moving) { B[k].x = c1[0] - c0[0]; B[k].y = c1[1] - c0[1]; B[k].z = c1[2] - c0[2]; }
+        else { B[k].x = B[k].y = B[k].z = (R)0.0; }
+        B[k].w = r;
+    }
+    std::vector<DevMaterial<R>> mats(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const mirt_material& m = d->materials[i];
+        mats[i].kind = m.kind; mats[i].tex = m.texture; mats[i].has_fuzz = m.has_fuzz; mats[i]._pad = 0;
+        mats[i].reflectance = (R)m.reflectance; mats[i].fuzz = (R)m.fuzz; mats[i].ior = (R)m.ior;
+        mats[i].albedo = {(R)m.albedo[0], (R)m.albedo[1], (R)m.albedo[2]};
+    }
+    std::vector<DevTexture<R>> texs(d->n_textures);
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const mirt_texture& t = d->textures[i];
+        texs[i].kind = t.kind; texs[i].image = t.image; texs[i].inv_scale = (R)t.inv_scale;
+        texs[i].even = {(R)t.color[0], (R)t.color[1], (R)t.color[2]};
+        texs[i].odd = {(R)t.odd[0], (R)t.odd[1], (R)t.odd[2]};
+    }
+    int rc;
+    if ((rc = upload(s, A, &out.A)) || (rc = upload(s, B, &out.B)) || (rc = upload(s, mats, &out.mats)) || (rc = upload(s, texs, &out.texs))) return rc;
+    return MIRT_OK;
+}
+
+template <class R> static DevScene<R> dev_scene(const mirt_scene* s, const SceneBuffers<R>& b) {
+    DevScene<R> d;
+    d.A = b.A; d.B = b.B; d.orig_id = s->orig_id; d.material = s->material; d.mats = b.mats; d.texs = b.texs;
+    d.imgs = s->imgs; d.texels = s->texels; d.n = s->n; d.n_static = s->n_static;
+    return d;
+}
+template <class R> static DevCamera<R> dev_camera(const mirt_camera* c) {
+    auto v = [](const double* p) { return V3<R>{(R)p[0], (R)p[1], (R)p[2]}; };
+    DevCamera<R> d;
+    d.lookfrom = v(c->lookfrom); d.du = v(c->px_du); d.dv = v(c->px_dv); d.ul = v(c->vp_upper_left); d.px00 = v(c->px00_loc);
+    d.disk_u = v(c->disk_u_r); d.disk_v = v(c->disk_v_r); d.defocus_angle = (R)c->defocus_angle;
+    d.W = c->img_width; d.H = c->img_height; d.spp = c->samples_per_pixel; d.depth = c->max_bounce_depth;
+    return d;
+}
+
+static int make_part(const mirt_camera* cam, const mirt_opts* o, DevPart* p) {
+    p->strip_rows = o->strip_rows ? o->strip_rows : 8u;
+    p->part_count = o->part_count ? o->part_count : 1u;
+    p->part_index = o->part_index;
+    if (p->part_index >= p->part_count) return fail(MIRT_ERR_INVALID, "mirt_opts: part_index >= part_count");
+    p->local_rows = part_rows(cam->img_height, p->strip_rows, p->part_index, p->part_count);
+    p->compact = (o->flags & MIRT_FLAG_COMPACT_ROWS) ? 1u : 0u;
+    return MIRT_OK;
+}
+static int check_common(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o) {
+    if (!s || !cam || !o) return fail(MIRT_ERR_INVALID, "null argument");
+    if (o->precision != MIRT_F32 && o->precision != MIRT_F64) return fail(MIRT_ERR_INVALID, "mirt_opts.precision must be 32 or 64");
+    if (cam->img_width == 0 || cam->img_height == 0) return fail(MIRT_ERR_INVALID, "empty image");
+    if ((uint64_t)cam->img_width * cam->img_height > 0xFFFFFFFFull) return fail(MIRT_ERR_TOO_LARGE, "W*H must fit 32 bits (RNG pixel counter)");
+    return MIRT_OK;
+}
+static uint32_t grid_for(uint32_t W, uint32_t local_rows) {
+    uint32_t tiles = ((W + 7) / 8) * ((local_rows + 7) / 8);
+    return (tiles + MIRT_WAVES_PER_BLOCK - 1) / MIRT_WAVES_PER_BLOCK;
+}
+
+/* ---- launches -------------------------------------------------------------------------------- */
+template <class R>
+static int launch_primary(const mirt_scene* s, const SceneBuffers<R>& b, const mirt_camera* cam, const DevPart& part, uint32_t* d_id, void* d_t,
+                          hipStream_t st) {
+    uint32_t grid = grid_for(cam->img_width, part.local_rows);
+    if (grid == 0) return MIRT_OK;
+    hipLaunchKernelGGL((primary_hits_kernel<R>), dim3(grid), dim3(MIRT_BLOCK), 0, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, d_id, (R*)d_t);
+    HIP_TRY(hipGetLastError());
+    return MIRT_OK;
+}
+template <class R>
+static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mirt_camera* cam, const DevPart& part, uint64_t seed, void* d_lin,
+                         uint8_t* d_rgb8, DevStats* d_stats, hipStream_t st) {
+    uint32_t grid = grid_for(cam->img_width, part.local_rows);
+    if (grid == 0) return MIRT_OK;
+    hipLaunchKernelGGL((render_kernel<R>), dim3(grid), dim3(MIRT_BLOCK), 0, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), (R*)d_lin, d_rgb8, d_stats);
+    HIP_TRY(hipGetLastError());
+    return MIRT_OK;
+}
+
+extern "C" {
+
+int mirt_abi_version(void) { return (int)MIRT_ABI_VERSION; }
+const char* mirt_last_error(void) { return g_err.c_str(); }
+int mirt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+uint32_t mirt_part_rows(uint32_t height, uint32_t strip_rows, uint32_t part_index, uint32_t part_count) {
+    return part_rows(height, strip_rows ? strip_rows : 8u, part_index, part_count);
+}
+void mirt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
+    if (!d || !out) return fail(MIRT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if ((d->n_spheres && !d->spheres) || (d->n_materials && !d->materials) || (d->n_textures && !d->textures) || (d->n_images && !d->images))
+        return fail(MIRT_ERR_INVALID, "scene description has a count without an array");
+    for (uint32_t i = 0; i < d->n_spheres; ++i)
+        if (d->spheres[i].material >= d->n_materials) return fail(MIRT_ERR_INVALID, "sphere references a material out of range");
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        if (d->materials[i].kind > MIRT_MAT_DIELECTRIC) return fail(MIRT_ERR_INVALID, "unknown material kind");
+        if (d->materials[i].kind == MIRT_MAT_LAMBERTIAN && d->materials[i].texture >= d->n_textures)
+            return fail(MIRT_ERR_INVALID, "material references a texture out of range");
+    }
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        if (d->textures[i].kind > MIRT_TEX_IMAGE) return fail(MIRT_ERR_INVALID, "unknown texture kind");
+        if (d->textures[i].kind == MIRT_TEX_IMAGE && d->textures[i].image >= d->n_images)
+            return fail(MIRT_ERR_INVALID, "texture references an image out of range");
+    }
+    for (uint32_t i = 0; i < d->n_images; ++i)
+        if ((uint64_t)d->images[i].width * d->images[i].height != 0 && !d->images[i].rgb) return fail(MIRT_ERR_INVALID, "image without texels");
+    int ndev = mirt_device_count();
+    if (ndev <= 0) return fail(MIRT_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(MIRT_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    mirt_scene* s = new (std::nothrow) mirt_scene();
+    if (!s) return fail(MIRT_ERR_NOMEM, "out of host memory");
+    s->device = device;
+    if (d->n_spheres > 0xFFFFFF00u) { delete s; return fail(MIRT_ERR_TOO_LARGE, "too many spheres"); }
+    /* statics first, each section in insertion order and padded to a whole broad-phase group */
+    std::vector<uint32_t> order;
+    order.reserve((size_t)d->n_spheres + 2 * MIRT_GROUP);
+    for (uint32_t i = 0; i < d->n_spheres; ++i)
+        if (!d->spheres[i].moving) order.push_back(i);
+    s->true_static = (uint32_t)order.size();
+    while (order.size() % MIRT_GROUP) order.push_back(0xFFFFFFFFu);
+    s->n_static = (uint32_t)order.size();
+    for (uint32_t i = 0; i < d->n_spheres; ++i)
+        if (d->spheres[i].moving) order.push_back(i);
+    while (order.size() % MIRT_GROUP) order.push_back(0xFFFFFFFFu);
+    s->n = (uint32_t)order.size();
+    s->true_n = d->n_spheres;
+    std::vector<uint32_t> mat(order.size());
+    for (size_t k = 0; k < order.size(); ++k) mat[k] = order[k] == 0xFFFFFFFFu ? 0u : d->spheres[order[k]].material;
+
+    /* images -> one RGBA8 pool (one dword per texel) */
+    std::vector<DevImage> imgs(d->n_images);
+    std::vector<uint32_t> texels;
+    for (uint32_t i = 0; i < d->n_images; ++i) {
+        const mirt_image& im = d->images[i];
+        imgs[i].w = im.width; imgs[i].h = im.height; imgs[i].offset = (uint32_t)texels.size(); imgs[i]._pad = 0;
+        size_t n = (size_t)im.width * im.height;
+        if (texels.size() + n > 0xFFFFFFFFull) { mirt_scene_destroy(s); return fail(MIRT_ERR_TOO_LARGE, "texture pool exceeds 2^32 texels"); }
+        for (size_t p = 0; p < n; ++p)
+            texels.push_back((uint32_t)im.rgb[3 * p] | ((uint32_t)im.rgb[3 * p + 1] << 8) | ((uint32_t)im.rgb[3 * p + 2] << 16));
+    }
+    int rc;
+    if ((rc = upload(s, order, &s->orig_id)) || (rc = upload(s, mat, &s->material)) || (rc = upload(s, imgs, &s->imgs)) ||
+        (rc = upload(s, texels, &s->texels)) || (rc = upload_real<float>(s, d, order, s->f32)) || (rc = upload_real<double>(s, d, order, s->f64))) {
+        mirt_scene_destroy(s);
+        return rc;
+    }
+    std::vector<DevStats> st(1);
+    memset(st.data(), 0, sizeof(DevStats));
+    if ((rc = upload(s, st, &s->stats))) { mirt_scene_destroy(s); return rc; }
+    *out = s;
+    return MIRT_OK;
+}
+
+void mirt_scene_destroy(mirt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (void* p : s->allocs) (void)hipFree(p);
+    delete s;
+}
+
+int mirt_primary_hits_device(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t* d_id, void* d_t, void* stream) {
+    int rc = check_common(s, cam, o);
+    if (rc) return rc;
+    if (!d_id) return fail(MIRT_ERR_INVALID, "id output is required");
+    DevPart part;
+    if ((rc = make_part(cam, o, &part))) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    return o->precision == MIRT_F64 ? launch_primary<double>(s, s->f64, cam, part, d_id, d_t, st)
+                                    : launch_primary<float>(s, s->f32, cam, part, d_id, d_t, st);
+}
+
+int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, void* d_lin, uint8_t* d_rgb8, void* stream,
+                       mirt_stats* stats) {
+    int rc = check_common(s, cam, o);
+    if (rc) return rc;
+    DevPart part;
+    if ((rc = make_part(cam, o, &part))) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (stats) {
+        HIP_TRY(hipMemsetAsync(s->stats, 0, sizeof(DevStats), st));
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    rc = o->precision == MIRT_F64 ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, stats ? s->stats : nullptr, st)
+                                  : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, stats ? s->stats : nullptr, st);
+    if (stats) {
+        if (!rc) {
+            hipError_t e = hipEventRecord(e1, st);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            DevStats h;
+            memset(&h, 0, sizeof(h));
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e == hipSuccess) e = hipMemcpy(&h, s->stats, sizeof(h), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = fail(MIRT_ERR_HIP, std::string("render: ") + hipGetErrorString(e));
+            memset(stats, 0, sizeof(*stats));
+            stats->segments = h.segments;
+            stats->static_tests = h.segments * (uint64_t)s->true_static;
+            stats->moving_tests = h.segments * (uint64_t)(s->true_n - s->true_static);
+            stats->sphere_tests = stats->static_tests + stats->moving_tests;
+            stats->narrow_tests = h.narrow;
+            stats->wave_iterations = h.wave_iters;
+            stats->nan_pixels = h.nan_pixels;
+            stats->kernel_ms = ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    return rc;
+}
+
+int mirt_primary_hits(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t* id, void* t) {
+    int rc = check_common(s, cam, o);
+    if (rc) return rc;
+    if (!id) return fail(MIRT_ERR_INVALID, "id output is required");
+    if (o->flags & MIRT_FLAG_COMPACT_ROWS) return fail(MIRT_ERR_INVALID, "host-buffer calls write full frames; use the _device entry point for compact bands");
+    HIP_TRY(hipSetDevice(s->device));
+    size_t npx = (size_t)cam->img_width * cam->img_height;
+    size_t rsz = o->precision == MIRT_F64 ? 8 : 4;
+    uint32_t* d_id = nullptr;
+    void* d_t = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_id, npx * 4));
+    if (hipMalloc(&d_t, npx * rsz) != hipSuccess) { (void)hipFree(d_id); return fail(MIRT_ERR_NOMEM, "hipMalloc failed"); }
+    /* rows outside this part keep MISS / +inf */
+    rc = MIRT_OK;
+    if (hipMemset(d_id, 0xFF, npx * 4) != hipSuccess) rc = fail(MIRT_ERR_HIP, "hipMemset failed");
+    if (!rc && hipMemset(d_t, 0, npx * rsz) != hipSuccess) rc = fail(MIRT_ERR_HIP, "hipMemset failed");
+    if (!rc) rc = mirt_primary_hits_device(s, cam, o, d_id, d_t, nullptr);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(MIRT_ERR_HIP, "primary_hits kernel failed");
+    if (!rc && hipMemcpy(id, d_id, npx * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
+    if (!rc && t && hipMemcpy(t, d_t, npx * rsz, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
+    (void)hipFree(d_id);
+    (void)hipFree(d_t);
+    return rc;
+}
+
+int mirt_render(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, void* lin, uint8_t* rgb8, mirt_stats* stats) {
+    int rc = check_common(s, cam, o);
+    if (rc) return rc;
+    if (o->flags & MIRT_FLAG_COMPACT_ROWS) return fail(MIRT_ERR_INVALID, "host-buffer calls write full frames; use the _device entry point for compact bands");
+    HIP_TRY(hipSetDevice(s->device));
+    size_t n = (size_t)cam->img_width * cam->img_height * 3;
+    size_t rsz = o->precision == MIRT_F64 ? 8 : 4;
+    void* d_lin = nullptr;
+    uint8_t* d_rgb8 = nullptr;
+    if (lin && hipMalloc(&d_lin, n * rsz) != hipSuccess) return fail(MIRT_ERR_NOMEM, "hipMalloc failed");
+    if (rgb8 && hipMalloc((void**)&d_rgb8, n) != hipSuccess) { (void)hipFree(d_lin); return fail(MIRT_ERR_NOMEM, "hipMalloc failed"); }
+    rc = MIRT_OK;
+    if (d_lin && hipMemset(d_lin, 0, n * rsz) != hipSuccess) rc = fail(MIRT_ERR_HIP, "hipMemset failed");
+    if (!rc && d_rgb8 && hipMemset(d_rgb8, 0, n) != hipSuccess) rc = fail(MIRT_ERR_HIP, "hipMemset failed");
+    mirt_stats local;
+    if (!rc) rc = mirt_render_device(s, cam, o, d_lin, d_rgb8, nullptr, &local);
+    if (!rc && lin && hipMemcpy(lin, d_lin, n * rsz, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
+    if (!rc && rgb8 && hipMemcpy(rgb8, d_rgb8, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
+    if (!rc && stats) *stats = local;
+    (void)hipFree(d_lin);
+    (void)hipFree(d_rgb8);
+    if (!rc && rgb8 && local.nan_pixels) return fail(MIRT_ERR_NAN, "a NaN reached the quantiser (the reference panics: rgb.rs:33)");
+    return rc;
+}
+
+int mirt_quantize_device(const void* d_linear, uint32_t precision, size_t n, uint8_t* d_out, void* stream, uint64_t* nan_count) {
+    if (!d_linear || !d_out) return fail(MIRT_ERR_INVALID, "null argument");
+    if (precision != MIRT_F32 && precision != MIRT_F64) return fail(MIRT_ERR_INVALID, "precision must be 32 or 64");
+    if (n == 0) { if (nan_count) *nan_count = 0; return MIRT_OK; }
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* d_nan = nullptr;
+    if (nan_count) {
+        HIP_TRY(hipMalloc((void**)&d_nan, 8));
+        HIP_TRY(hipMemsetAsync(d_nan, 0, 8, st));
+    }
+    uint32_t grid = (uint32_t)((n + 255) / 256);
+    if (precision == MIRT_F64) hipLaunchKernelGGL((quantize_kernel<double>), dim3(grid), dim3(256), 0, st, (const double*)d_linear, n, d_out, d_nan);
+    else hipLaunchKernelGGL((quantize_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)d_linear, n, d_out, d_nan);
+    HIP_TRY(hipGetLastError());
+    if (nan_count) {
+        unsigned long long h = 0;
+        hipError_t e = hipMemcpyAsync(&h, d_nan, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_nan);
+        if (e != hipSuccess) return fail(MIRT_ERR_HIP, hipGetErrorString(e));
+        *nan_count = h;
+    }
+    return MIRT_OK;
+}
+
+int mirt_deinterleave_device(const void* d_bands, size_t band_stride_bytes, uint32_t part_count, uint32_t strip_rows, uint32_t width,
+                             uint32_t height, uint32_t elem_bytes, void* d_frame, void* stream) {
+    if (!d_bands || !d_frame || part_count == 0 || elem_bytes == 0) return fail(MIRT_ERR_INVALID, "bad argument");
+    if (strip_rows == 0) strip_rows = 8;
+    size_t total = (size_t)width * height * elem_bytes;
+    if (total == 0) return MIRT_OK;
+    size_t need = (size_t)part_rows(height, strip_rows, 0, part_count) * width * elem_bytes;
+    if (band_stride_bytes < need) return fail(MIRT_ERR_INVALID, "band_stride_bytes smaller than the largest band");
+    size_t grid = (total + 255) / 256;
+    if (grid > 0x7FFFFFFFull) return fail(MIRT_ERR_TOO_LARGE, "frame too large");
+    hipLaunchKernelGGL(deinterleave_kernel, dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_bands, band_stride_bytes,
+                       part_count, strip_rows, width, height, elem_bytes, (uint8_t*)d_frame);
+    HIP_TRY(hipGetLastError());
+    return MIRT_OK;
+}
+
+} /* extern "C" */

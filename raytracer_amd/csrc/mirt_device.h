@@ -1,0 +1,161 @@
+/*
+ * mirt_device.h — device-side building blocks of the gfx950 render backend (product code; does not
+ * include or call anything under oracle/).
+ *
+ * Everything is templated on Real:
+ *   double : parity mode.  The reference's f64 operation sequence, one IEEE operation per source
+ *            operation (the whole library is compiled with -ffp-contract=off).
+ *   float  : throughput mode.  Same sequence in binary32, except the sphere discriminant, whose
+ *            products are fused with explicit fmaf (the "f32 spec" of DESIGN.md).
+ *
+ * Reference citations are /root/reference/src/<file>:<line>.
+ */
+#ifndef MIRT_DEVICE_H
+#define MIRT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mirt.h"
+
+#define MIRT_WAVE 64
+#define MIRT_WAVES_PER_BLOCK 4
+#define MIRT_BLOCK (MIRT_WAVE * MIRT_WAVES_PER_BLOCK)
+#define MIRT_TILE 64   /* spheres staged per LDS tile, one per lane */
+#define MIRT_GROUP 4    /* spheres per broad-phase group */
+#define MIRT_CAND_CAP 16 /* deferred narrow-phase candidates kept per lane */
+
+namespace mirt {
+
+/* ---- small vector type (core/point3.rs) -------------------------------------------------------- */
+template <class R> struct V3 {
+    R x, y, z;
+};
+template <class R> __host__ __device__ inline V3<R> operator+(V3<R> a, V3<R> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class R> __host__ __device__ inline V3<R> operator-(V3<R> a, V3<R> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class R> __host__ __device__ inline V3<R> operator*(V3<R> a, R l) { return {a.x * l, a.y * l, a.z * l}; }
+template <class R> __host__ __device__ inline V3<R> operator/(V3<R> a, R l) { return {a.x / l, a.y / l, a.z / l}; }
+template <class R> __host__ __device__ inline V3<R> operator-(V3<R> a) { return {-a.x, -a.y, -a.z}; }
+template <class R> __host__ __device__ inline R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; } /* point3.rs:52-58 */
+
+__device__ inline float m_sqrt(float x) { return sqrtf(x); }
+__device__ inline double m_sqrt(double x) { return sqrt(x); }
+__device__ inline float m_fabs(float x) { return fabsf(x); }
+__device__ inline double m_fabs(double x) { return fabs(x); }
+__device__ inline float m_fmin(float a, float b) { return fminf(a, b); }
+__device__ inline double m_fmin(double a, double b) { return fmin(a, b); }
+__device__ inline float m_floor(float x) { return floorf(x); }
+__device__ inline double m_floor(double x) { return floor(x); }
+__device__ inline float m_round(float x) { return roundf(x); }
+__device__ inline double m_round(double x) { return round(x); }
+__device__ inline float m_acos(float x) { return acosf(x); }
+__device__ inline double m_acos(double x) { return acos(x); }
+__device__ inline float m_atan2(float y, float x) { return atan2f(y, x); }
+__device__ inline double m_atan2(double y, double x) { return atan2(y, x); }
+__device__ inline float m_sin(float x) { return sinf(x); }
+__device__ inline double m_sin(double x) { return sin(x); }
+__device__ inline float m_cos(float x) { return cosf(x); }
+__device__ inline double m_cos(double x) { return cos(x); }
+
+template <class R> __device__ inline V3<R> unit(V3<R> a) { return a / m_sqrt(dot(a, a)); } /* point3.rs:39-46 */
+template <class R> __device__ inline V3<R> reflect(V3<R> v, V3<R> n) { return v - (n * (R)2.0) * dot(v, n); } /* point3.rs:116-118 */
+
+/* ---- 4-wide sphere records ------------------------------------------------------------------------ */
+template <class R> struct Vec4;
+template <> struct Vec4<float> { typedef float4 type; };
+template <> struct Vec4<double> { typedef double4 type; };
+
+/* ---- flattened scene in HBM (see DESIGN.md "Data layout") ---------------------------------------- */
+struct DevImage {
+    uint32_t w, h;
+    uint32_t offset; /* first texel in the RGBA8 pool (one dword per texel, A unused) */
+    uint32_t _pad;
+};
+template <class R> struct DevTexture {
+    uint32_t kind, image;
+    R inv_scale;
+    V3<R> even, odd;
+};
+template <class R> struct DevMaterial {
+    uint32_t kind, tex, has_fuzz, _pad;
+    R reflectance, fuzz, ior;
+    V3<R> albedo;
+};
+template <class R> struct DevScene {
+    /* spheres, statics first: [0, n_static) static, [n_static, n) moving; both counts are padded to a
+     * multiple of MIRT_GROUP with dummy records (r*r = -inf -> never a candidate, orig_id = ~0u) */
+    const typename Vec4<R>::type* A; /* (c0.x, c0.y, c0.z, r*r)                 */
+    const typename Vec4<R>::type* B; /* (c1-c0).x, .y, .z, r                    */
+    const uint32_t* orig_id;         /* sorted index -> hit id (index in mirt_scene_desc.spheres) */
+    const uint32_t* material;        /* sorted index -> material                */
+    const DevMaterial<R>* mats;
+    const DevTexture<R>* texs;
+    const DevImage* imgs;
+    const uint32_t* texels;          /* RGBA8 pool                              */
+    uint32_t n, n_static;
+};
+template <class R> struct DevCamera { /* struct Camera, camera/camera.rs:107-120, rounded once to Real */
+    V3<R> lookfrom, du, dv, ul, px00, disk_u, disk_v;
+    R defocus_angle;
+    uint32_t W, H, spp, depth;
+};
+struct DevPart { /* interleaved row strips (mirt_opts) */
+    uint32_t strip_rows, part_index, part_count, local_rows, compact;
+};
+
+__host__ __device__ inline uint32_t part_rows(uint32_t height, uint32_t S, uint32_t idx, uint32_t cnt) {
+    if (cnt <= 1) return height;
+    uint32_t rows = 0;
+    uint32_t nstrips = (height + S - 1) / S;
+    for (uint32_t s = idx; s < nstrips; s += cnt) {
+        uint32_t r0 = s * S, r1 = r0 + S;
+        rows += (r1 > height ? height : r1) - r0;
+    }
+    return rows;
+}
+/* local (compact) row -> global row */
+__host__ __device__ inline uint32_t part_global_row(const DevPart& p, uint32_t lr) {
+    if (p.part_count <= 1) return lr;
+    uint32_t ls = lr / p.strip_rows, within = lr - ls * p.strip_rows;
+    return (ls * p.part_count + p.part_index) * p.strip_rows + within;
+}
+
+/* ---- counter-based RNG: Philox4x32-10 (Salmon et al., SC'11) --------------------------------------
+ * ctr = (pixel, sample, bounce, block), key = (seed_lo, seed_hi).  Each block yields two uniforms:
+ * word pairs (x0|x1<<32) and (x2|x3<<32); f64 draw = (u64>>11)*2^-53, f32 draw = (u64>>40)*2^-24. */
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r > 0) {
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ inline double u01_from(uint32_t lo, uint32_t hi, double) {
+    uint64_t u = (uint64_t)lo | ((uint64_t)hi << 32);
+    return (double)(u >> 11) * 0x1.0p-53;
+}
+__device__ inline float u01_from(uint32_t, uint32_t hi, float) { return (float)(hi >> 8) * 0x1.0p-24f; }
+
+template <class R> struct Draws {
+    uint32_t pixel, sample, bounce, k0, k1;
+    __device__ inline void block(uint32_t blk, R& a, R& b) const {
+        uint32_t o[4];
+        philox4x32_10(pixel, sample, bounce, blk, k0, k1, o);
+        a = u01_from(o[0], o[1], (R)0);
+        b = u01_from(o[2], o[3], (R)0);
+    }
+};
+
+} /* namespace mirt */
+#endif

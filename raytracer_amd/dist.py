@@ -1,0 +1,46 @@
+"""Multi-GPU sharding of the image: one process per GPU, interleaved row strips, one exchange
+step - the per-rank bands are gathered with torch.distributed (backend "nccl" = RCCL over xGMI) and scattered
+back into frame order by kernel K4 (mirt_deinterleave_device).  The scene is replicated on every rank; the
+counter-based RNG makes the image independent of the number of ranks.
+
+The bookkeeping is plain integer arithmetic and is tested on CPU (gloo, world_size 2) with synthetic bands.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+DEFAULT_STRIP_ROWS = 8
+
+
+def owned_rows(height: int, strip_rows: int, part_index: int, part_count: int) -> np.ndarray:
+    """Global row numbers rendered by `part_index`, in band (local) order."""
+    s = strip_rows or DEFAULT_STRIP_ROWS
+    rows = np.arange(height)
+    return rows[(rows // s) % max(part_count, 1) == part_index]
+
+
+def part_rows(height: int, strip_rows: int, part_index: int, part_count: int) -> int:
+    return int(len(owned_rows(height, strip_rows, part_index, part_count)))
+
+
+def deinterleave_host(bands: np.ndarray, height: int, strip_rows: int) -> np.ndarray:
+    """Host restatement of K4 for tests: bands[r, local_row] -> frame[global_row]."""
+    n = bands.shape[0]
+    frame = np.empty((height,) + bands.shape[2:], bands.dtype)
+    for r in range(n):
+        rows = owned_rows(height, strip_rows, r, n)
+        frame[rows] = bands[r, : len(rows)]
+    return frame
+
+
+def gather_bands(band, world_size: int):
+    """All ranks contribute an equally sized band tensor (rank 0's size is the largest: pad to it); returns the
+    stacked (world_size, ...) tensor on every rank.  On ROCm the 'nccl' backend is RCCL."""
+    import torch
+    import torch.distributed as td
+
+    if world_size == 1:
+        return band.unsqueeze(0)
+    out = torch.empty((world_size,) + tuple(band.shape), dtype=band.dtype, device=band.device)
+    td.all_gather_into_tensor(out, band.contiguous())
+    return out

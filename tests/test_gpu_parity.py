@@ -1,0 +1,324 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden maps.  Needs a GPU.
+
+Bars (BASELINE.json):
+  * hit-id / t maps of deterministic primary rays: BIT-EXACT at equal precision (f64 vs f64 oracle, f32 vs f32 oracle)
+  * quantiser: byte-exact given equal linear input
+  * radiance with the shared counter-based RNG: per-pixel tolerance stated in each test (the GPU multiplies the
+    attenuations front to back, the recursion back to front, and libm differs from OCML in the last ulp, so a
+    handful of samples may take a different branch)
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, presets
+from raytracer_amd.api import Camera, CheckerTexture, Dielectric, ImageTexture, Lambertian, Metal, Scene, Sphere
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+def psnr(a, b):
+    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    return 99.0 if mse == 0 else 10.0 * math.log10(1.0 / mse)
+
+
+SCENES = {
+    "mars": (presets.mars_texture_scene, lambda w, s, d=50: presets.default_camera(w, s, d)),
+    "balls": (lambda: presets.bouncing_balls_scene(1), lambda w, s, d=50: presets.bouncing_balls_camera(w, s, d)),
+}
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    return {k: mk() for k, (mk, _) in SCENES.items()}
+
+
+# ---- K1: hit-id maps, bit exact ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mars", "balls"])
+@pytest.mark.parametrize("prec", [abi.F64, abi.F32])
+def test_hit_id_map_bit_exact_vs_oracle(oracle, scenes, name, prec):
+    sc = scenes[name]
+    cam = SCENES[name][1](400, 0)
+    ids, t = cam.primary_hits(sc, precision=prec)
+    o_ids, o_t = oracle.primary_hits(sc.flat, cam.pod, prec, use_bvh=(prec == abi.F64))
+    assert np.array_equal(ids, o_ids)
+    assert np.array_equal(bits(t), bits(o_t))
+    assert (ids != abi.MISS_ID).any() and (ids == abi.MISS_ID).any()
+
+
+@pytest.mark.parametrize("name", ["mars", "balls"])
+def test_hit_id_map_matches_committed_golden(golden_dir, scenes, name):
+    g = np.load(os.path.join(golden_dir, "oracle_maps.npz"))
+    for w in (64, 400):
+        for prec, tag in ((abi.F64, "f64"), (abi.F32, "f32")):
+            ids, t = SCENES[name][1](w, 0).primary_hits(scenes[name], precision=prec)
+            assert np.array_equal(ids, g[f"{name}_{w}_{tag}_id"])
+            assert np.array_equal(bits(t), bits(g[f"{name}_{w}_{tag}_t"]))
+
+
+def test_hit_id_map_1080p_bit_exact(oracle, scenes):
+    """BASELINE.json configs[1]/[2] size: full 1920x1080 map of the ~485-sphere scene, f64 and f32."""
+    sc = scenes["balls"]
+    cam = presets.bouncing_balls_camera(1920, 0, 50)
+    for prec in (abi.F64, abi.F32):
+        ids, t = cam.primary_hits(sc, precision=prec)
+        o_ids, o_t = oracle.primary_hits(sc.flat, cam.pod, prec, use_bvh=(prec == abi.F64))
+        assert int((ids != o_ids).sum()) == 0
+        assert np.array_equal(bits(t), bits(o_t))
+
+
+def test_f32_vs_f64_id_mismatch_is_a_handful_of_edge_pixels(scenes):
+    cam = presets.bouncing_balls_camera(1920, 0, 50)
+    a, _ = cam.primary_hits(scenes["balls"], precision=abi.F64)
+    b, _ = cam.primary_hits(scenes["balls"], precision=abi.F32)
+    assert (a != b).mean() < 1e-3
+
+
+# ---- closest-hit edge cases --------------------------------------------------------------------------------------------
+def _cam(w=32, ratio=1.0, spp=0, depth=10, lookfrom=None, lookat=None, vfov=None):
+    return Camera.build(lookfrom, lookat, None, w, ratio, spp, vfov, None, None, depth)
+
+
+def _check_map(oracle, sc, cam):
+    for prec in (abi.F64, abi.F32):
+        ids, t = cam.primary_hits(sc, precision=prec)
+        o_ids, o_t = oracle.primary_hits(sc.flat, cam.pod, prec)
+        assert np.array_equal(ids, o_ids) and np.array_equal(bits(t), bits(o_t))
+    return ids
+
+
+def test_empty_scene_is_all_miss(oracle):
+    sc = Scene()
+    sc.build_bvh()
+    ids = _check_map(oracle, sc, _cam(19, 1.7))
+    assert (ids == abi.MISS_ID).all()
+    lin, rgb8 = _cam(19, 1.7, spp=2).render_arrays(sc, precision=abi.F32, seed=1)
+    assert np.isfinite(lin).all() and (rgb8 > 100).all()  # sky everywhere
+
+
+def test_ties_go_to_lowest_id_and_duplicates(oracle):
+    sc = Scene()
+    m = Lambertian.new((1, 1, 1), 1.0)
+    # ids: 0 moving (sorted AFTER the statics on the device), 1 and 2 static twins of it at tm = 0
+    sc.add(Sphere.new(1.0, (0, 0, -5), (0, 0, -5), m))
+    sc.add(Sphere.new_static(1.0, (0, 0, -5), m))
+    sc.add(Sphere.new_static(1.0, (0, 0, -5), m))
+    sc.build_bvh()
+    ids = _check_map(oracle, sc, _cam(24))
+    assert set(np.unique(ids)) == {0, abi.MISS_ID}
+
+
+def test_candidate_list_overflow_flush(oracle):
+    """More than MIRT_CAND_CAP spheres along one ray: 40 concentric shells + 30 spheres in a row behind each other."""
+    sc = Scene()
+    m = Lambertian.new((1, 1, 1), 1.0)
+    for k in range(40):
+        sc.add(Sphere.new_static(3.0 - 0.05 * k, (0, 0, -6), m))
+    for k in range(30):
+        sc.add(Sphere.new(0.4, (0.5, 0.5, -12.0 - k), (0.5, 0.6, -12.0 - k), m))
+    sc.build_bvh()
+    ids = _check_map(oracle, sc, _cam(40))
+    assert (ids == 0).any()
+    # from inside all shells: far roots, the innermost shell (id 39) wins
+    ids = _check_map(oracle, sc, _cam(16, lookfrom=(0, 0, -6), lookat=(0, 0, -7)))
+    assert (ids == 39).all()
+
+
+def test_many_tiles_moving_and_static_mix(oracle):
+    rng = np.random.default_rng(5)
+    sc = Scene()
+    for k in range(333):  # > 5 tiles of 64, odd counts to exercise the group padding
+        c = tuple(rng.uniform(-6, 6, 3) + np.array([0, 0, -14.0]))
+        mat = [Lambertian.new((0.5, 0.5, 0.5), 0.9), Metal.new((0.8, 0.8, 0.8), 0.1), Dielectric.new(1.5)][k % 3]
+        if k % 5 < 2:
+            sc.add(Sphere.new(float(rng.uniform(0.1, 0.6)), c, (c[0], c[1] + 0.3, c[2]), mat))
+        else:
+            sc.add(Sphere.new_static(float(rng.uniform(0.1, 0.6)), c, mat))
+    sc.build_bvh()
+    ids = _check_map(oracle, sc, _cam(97, 1.3))  # width not a multiple of the 8x8 wave tile
+    assert len(np.unique(ids)) > 50
+
+
+def test_one_pixel_image_and_tall_image(oracle, scenes):
+    _check_map(oracle, scenes["mars"], Camera.build((0, 0, 12), (0, 0, 0), None, 1, 1.0, 0, 0.4, 10.0, None, 5))
+    _check_map(oracle, scenes["mars"], Camera.build((0, 0, 12), (0, 0, 0), None, 3, 0.02, 0, 0.4, 10.0, None, 5))
+
+
+# ---- K2: radiance -------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mars", "balls"])
+@pytest.mark.parametrize("prec", [abi.F64, abi.F32])
+def test_radiance_vs_oracle_same_rng(oracle, scenes, name, prec):
+    """Same seeded counter RNG on both sides.  Tolerance: >= 99.5 % of the channels agree to 1e-9 (f64) / 2e-5 (f32)
+    relative-absolute; whole-image PSNR >= 50 dB (f64) / 45 dB (f32); no pixel off by more than 0.25 (a single
+    sample of 16 taking another branch moves a channel by at most 1.25/16)."""
+    sc = scenes[name]
+    cam = SCENES[name][1](96, 16)
+    lin, rgb8 = cam.render_arrays(sc, precision=prec, seed=7)
+    o_lin, o_rgb8, o_seg, o_nan = oracle.render(sc.flat, cam.pod, prec, seed=7, threads=8)
+    assert o_nan == 0 and np.isfinite(lin).all()
+    err = np.abs(lin.astype(np.float64) - o_lin.astype(np.float64))
+    tol = 1e-9 if prec == abi.F64 else 2e-5
+    frac_close = float((err <= tol * (1.0 + np.abs(o_lin))).mean())
+    assert frac_close >= 0.995, frac_close
+    assert err.max() <= 0.25, err.max()
+    assert psnr(lin, o_lin) >= (50.0 if prec == abi.F64 else 45.0)
+    # exact segment count unless a path branched differently
+    assert abs(cam.last_stats["segments"] - o_seg) <= 0.002 * o_seg
+    assert (np.abs(rgb8.astype(int) - o_rgb8.astype(int)) <= 1).mean() >= 0.995
+
+
+@pytest.mark.parametrize("name", ["mars", "balls"])
+def test_radiance_matches_committed_golden(golden_dir, scenes, name):
+    g = np.load(os.path.join(golden_dir, "oracle_maps.npz"))
+    cam = SCENES[name][1](64, 16)
+    for prec, tag, tol in ((abi.F64, "f64", 1e-9), (abi.F32, "f32", 2e-5)):
+        lin, _ = cam.render_arrays(scenes[name], precision=prec, seed=7)
+        ref = g[f"{name}_64x16spp_{tag}_lin"]
+        err = np.abs(lin.astype(np.float64) - ref.astype(np.float64))
+        assert float((err <= tol * (1.0 + np.abs(ref))).mean()) >= 0.995 and err.max() <= 0.25
+
+
+def test_no_aa_render_is_deterministic_branch(oracle, scenes):
+    """samples_per_pixel == 0 (Some(0)): one path per pixel through the pixel CORNER, tm = 0 (camera.rs:247-254)."""
+    sc = scenes["balls"]
+    cam = presets.bouncing_balls_camera(160, 0, 50)
+    lin, _ = cam.render_arrays(sc, precision=abi.F64, seed=3)
+    o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F64, seed=3, threads=8)
+    err = np.abs(lin - o_lin)
+    assert float((err <= 1e-12).mean()) >= 0.999
+
+
+def test_depth_limits(oracle, scenes):
+    sc = scenes["balls"]
+    for depth in (0, 1, 2):
+        cam = presets.bouncing_balls_camera(64, 4, depth)
+        lin, _ = cam.render_arrays(sc, precision=abi.F64, seed=1)
+        o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F64, seed=1, threads=4)
+        assert cam.last_stats["segments"] == o_seg
+        assert np.abs(lin - o_lin).max() <= 1e-12
+        if depth == 0:
+            assert (lin == 0).all() and o_seg == 0
+
+
+def test_image_independent_of_partition(scenes):
+    """Interleaved strips over 1, 2, 3 parts give bit-identical pixels (counter RNG keyed on the global pixel)."""
+    sc = scenes["balls"]
+    cam = presets.bouncing_balls_camera(80, 4, 50)
+    lib = abi.load()
+    ds = sc.device_scene(0)
+    H, W = cam.height, cam.width
+    full, _ = cam.render_arrays(sc, precision=abi.F32, seed=9)
+    for n in (2, 3):
+        acc = np.zeros_like(full)
+        for r in range(n):
+            part = np.zeros_like(full)
+            o = cam.opts(precision=abi.F32, seed=9, strip_rows=8, part_index=r, part_count=n)
+            abi.check(lib.mirt_render(ds.handle, C.byref(cam.pod), C.byref(o), part.ctypes.data, None, None))
+            acc += part  # rows not owned stay zero
+        assert np.array_equal(acc, full)
+
+
+def test_run_to_run_bit_stable(scenes):
+    cam = presets.bouncing_balls_camera(64, 8, 50)
+    a, _ = cam.render_arrays(scenes["balls"], precision=abi.F32, seed=2)
+    b, _ = cam.render_arrays(scenes["balls"], precision=abi.F32, seed=2)
+    c, _ = cam.render_arrays(scenes["balls"], precision=abi.F32, seed=3)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def test_textured_scene_psnr_f32_vs_f64_oracle(oracle):
+    """Throughput mode against the reference's arithmetic (f64 oracle): statistical agreement only."""
+    sc = presets.textured_scene()
+    cam = presets.textured_camera(96, 32, 50)
+    lin, _ = cam.render_arrays(sc, precision=abi.F32, seed=4)
+    o_lin, _, _, _ = oracle.render(sc.flat, cam.pod, abi.F64, seed=4, threads=8)
+    assert psnr(lin, o_lin) >= 30.0
+
+
+# ---- K3 / K4 / device entry points -------------------------------------------------------------------------------------
+def test_quantiser_byte_exact(oracle):
+    import torch
+
+    lib = abi.load()
+    rng = np.random.default_rng(0)
+    for dt, prec in ((np.float64, abi.F64), (np.float32, abi.F32)):
+        x = np.concatenate([rng.random(100001) * 1.3 - 0.1, [0.0, -0.0, 1.0, 4.0, 0.25, np.nan, np.inf, 1e-30, (127.5 / 254.999) ** 2]]).astype(dt)
+        want, _ = oracle.quantize(x)
+        d_x = torch.from_numpy(x).cuda()
+        d_o = torch.empty(x.size, dtype=torch.uint8, device="cuda")
+        nan = C.c_uint64(123)
+        abi.check(lib.mirt_quantize_device(d_x.data_ptr(), prec, x.size, d_o.data_ptr(), None, C.byref(nan)))
+        assert np.array_equal(d_o.cpu().numpy(), want) and nan.value == 0
+
+
+def test_device_entry_points_and_deinterleave(scenes):
+    import torch
+
+    from raytracer_amd import dist
+
+    lib = abi.load()
+    sc = scenes["balls"]
+    cam = presets.bouncing_balls_camera(72, 2, 50)
+    ds = sc.device_scene(0)
+    H, W = cam.height, cam.width
+    full, full8 = cam.render_arrays(sc, precision=abi.F32, seed=5)
+    n, S = 3, 8
+    rows0 = dist.part_rows(H, S, 0, n)
+    bands = torch.zeros((n, rows0, W, 3), dtype=torch.float32, device="cuda")
+    bands8 = torch.zeros((n, rows0, W, 3), dtype=torch.uint8, device="cuda")
+    for r in range(n):
+        o = cam.opts(precision=abi.F32, seed=5, strip_rows=S, part_index=r, part_count=n, flags=abi.FLAG_COMPACT_ROWS)
+        st = abi.MirtStats()
+        abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(o), bands[r].data_ptr(), bands8[r].data_ptr(), None, C.byref(st)))
+        assert st.segments > 0 and st.kernel_ms > 0
+    frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    frame8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    abi.check(lib.mirt_deinterleave_device(bands.data_ptr(), bands[0].numel() * 4, n, S, W, H, 12, frame.data_ptr(), None))
+    abi.check(lib.mirt_deinterleave_device(bands8.data_ptr(), bands8[0].numel(), n, S, W, H, 3, frame8.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), full) and np.array_equal(frame8.cpu().numpy(), full8)
+    assert np.array_equal(dist.deinterleave_host(bands.cpu().numpy(), H, S), full)
+    # compact primary hits
+    ids_full, t_full = cam.primary_hits(sc, precision=abi.F32)
+    d_id = torch.full((rows0, W), 7, dtype=torch.int32, device="cuda")
+    d_t = torch.zeros((rows0, W), dtype=torch.float32, device="cuda")
+    o = cam.opts(precision=abi.F32, strip_rows=S, part_index=1, part_count=n, flags=abi.FLAG_COMPACT_ROWS)
+    abi.check(lib.mirt_primary_hits_device(ds.handle, C.byref(cam.pod), C.byref(o), d_id.data_ptr(), d_t.data_ptr(), None))
+    torch.cuda.synchronize()
+    rows = dist.owned_rows(H, S, 1, n)
+    assert np.array_equal(d_id.cpu().numpy().view(np.uint32)[: len(rows)], ids_full[rows])
+
+
+def test_error_codes_on_gpu(scenes):
+    lib = abi.load()
+    cam = presets.default_camera(16, 1, 5)
+    ds = scenes["mars"].device_scene(0)
+    o = cam.opts(precision=16)
+    assert lib.mirt_render(ds.handle, C.byref(cam.pod), C.byref(o), None, None, None) == -1
+    o = cam.opts(precision=abi.F32, part_index=2, part_count=2)
+    assert lib.mirt_render(ds.handle, C.byref(cam.pod), C.byref(o), None, None, None) == -1
+    h = C.c_void_p()
+    assert lib.mirt_scene_create(C.byref(scenes["mars"].flat.desc), 99, C.byref(h)) == -2
+    assert lib.mirt_device_count() >= 1
+
+
+def test_ppm_output_matches_oracle_bytes(oracle, scenes):
+    """Camera::render drop-in: header + one 'r g b' line per pixel; bytes equal the oracle's for the no-AA branch."""
+    import io
+
+    from raytracer_amd.api import ppm_body
+
+    sc = scenes["mars"]
+    cam = presets.default_camera(64, 0, 50)
+    buf = io.BytesIO()
+    cam.precision = abi.F64
+    cam.render(sc, out=buf)
+    _, o_rgb8, _, _ = oracle.render(sc.flat, cam.pod, abi.F64, seed=0, threads=4)
+    assert buf.getvalue() == b"P3\n64 36\n255\n" + ppm_body(o_rgb8)
