@@ -137,6 +137,14 @@ def load():
             f"{LIB_PATH} not found - the HIP extension is not built. Run `make -C raytracer_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback."
         )
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7 and cannot initialise the GPU once
+    # /opt/rocm's copy has been loaded (and vice versa).  Importing torch first makes the dynamic linker resolve
+    # libmirt.so's libamdhip64.so.7 to the copy torch already loaded, so torch tensors (device memory, streams,
+    # torch.distributed/RCCL) and the mirt kernels share a runtime.  Without torch the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, u32, u64, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
     P = C.POINTER
