@@ -117,7 +117,7 @@ EXPORTS = [
 ]
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "csrc", "libmirt.so")
+LIB_PATH = os.environ.get("MIRT_LIB") or os.path.join(_PKG_DIR, "csrc", "libmirt.so")  # MIRT_LIB: A/B builds of the kernels
 _lib = None
 
 

@@ -16,6 +16,10 @@
 
 using namespace mirt;
 
+#ifndef MIRT_F32_MIN_WAVES
+#define MIRT_F32_MIN_WAVES 6 /* __launch_bounds__ waves per SIMD for the f32 render kernel (A/B on MI355X: 6 beats 4 and 8) */
+#endif
+
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -43,6 +47,10 @@ struct mirt_scene {
     DevImage* imgs = nullptr;
     DevStats* stats = nullptr; /* one per scene: calls on one scene handle are not re-entrant */
     std::vector<void*> allocs;
+    /* render workspace (per-item partial sums), grown on demand and kept until the scene is destroyed */
+    mutable void* partial = nullptr;
+    mutable size_t partial_bytes = 0;
+    int n_cus = 256;
 };
 
 template <class T> static int upload(mirt_scene* s, const std::vector<T>& host, T** dev) {
@@ -138,13 +146,55 @@ static int launch_primary(const mirt_scene* s, const SceneBuffers<R>& b, const m
     HIP_TRY(hipGetLastError());
     return MIRT_OK;
 }
-template <class R>
+/* Samples per work item: the partial-sum workspace is capped at MIRT_PARTIAL_BUDGET bytes, and an item should not
+ * be smaller than 4 samples (per-item bookkeeping) unless the pixel has fewer. */
+#define MIRT_PARTIAL_BUDGET (512ull << 20)
+static void choose_chunks(uint64_t n_pixels, uint32_t nsamples, size_t real_bytes, uint32_t* chunk, uint32_t* chunks) {
+    uint64_t max_chunks = MIRT_PARTIAL_BUDGET / (std::max<uint64_t>(n_pixels, 1) * 3 * real_bytes);
+    if (max_chunks < 1) max_chunks = 1;
+    uint32_t q = nsamples >= 8 ? 4u : 1u; /* 64 spp -> 16 items of 4 samples per pixel */
+    while ((nsamples + q - 1) / q > max_chunks) q *= 2;
+    *chunk = q;
+    *chunks = (nsamples + q - 1) / q;
+}
+
+template <class R, int MIN_WAVES>
 static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mirt_camera* cam, const DevPart& part, uint64_t seed, void* d_lin,
-                         uint8_t* d_rgb8, DevStats* d_stats, hipStream_t st) {
-    uint32_t grid = grid_for(cam->img_width, part.local_rows);
-    if (grid == 0) return MIRT_OK;
-    hipLaunchKernelGGL((render_kernel<R>), dim3(grid), dim3(MIRT_BLOCK), 0, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, (uint32_t)seed,
-                       (uint32_t)(seed >> 32), (R*)d_lin, d_rgb8, d_stats);
+                         uint8_t* d_rgb8, hipStream_t st) {
+    uint64_t n_pixels = (uint64_t)cam->img_width * part.local_rows;
+    if (n_pixels == 0) return MIRT_OK;
+    RenderParams rp;
+    rp.nsamples = cam->samples_per_pixel ? cam->samples_per_pixel : 1u;
+    choose_chunks(n_pixels, rp.nsamples, sizeof(R), &rp.chunk, &rp.chunks);
+    if (n_pixels * rp.chunks > 0xFFFFFF00ull) return fail(MIRT_ERR_TOO_LARGE, "too many work items for one launch");
+    rp.n_items = (uint32_t)(n_pixels * rp.chunks);
+    rp.k0 = (uint32_t)seed;
+    rp.k1 = (uint32_t)(seed >> 32);
+    size_t need = (size_t)rp.n_items * 3 * sizeof(R);
+    if (need > s->partial_bytes) {
+        if (s->partial) (void)hipFree(s->partial);
+        s->partial = nullptr;
+        s->partial_bytes = 0;
+        HIP_TRY(hipMalloc(&s->partial, need));
+        s->partial_bytes = need;
+    }
+    if (cam->max_bounce_depth == 0) {
+        /* color(ray, 0) is black before any hit test (camera.rs:269-271): no segment is traced */
+        HIP_TRY(hipMemsetAsync(s->partial, 0, need, st));
+    } else {
+        /* persistent grid: as many blocks as can be resident, every wave pulls items until the queue is empty */
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<R, MIN_WAVES>, MIRT_BLOCK, 0));
+        if (per_cu < 1) per_cu = 1;
+        uint64_t waves_needed = ((uint64_t)rp.n_items + 63) / 64;
+        uint64_t grid = std::min<uint64_t>((uint64_t)s->n_cus * per_cu, (waves_needed + MIRT_WAVES_PER_BLOCK - 1) / MIRT_WAVES_PER_BLOCK);
+        hipLaunchKernelGGL((render_kernel<R, MIN_WAVES>), dim3((uint32_t)grid), dim3(MIRT_BLOCK), 0, st, dev_scene<R>(s, b), dev_camera<R>(cam), part,
+                           rp, (R*)s->partial, s->stats);
+        HIP_TRY(hipGetLastError());
+    }
+    uint32_t rgrid = (uint32_t)((n_pixels + 255) / 256);
+    hipLaunchKernelGGL((resolve_kernel<R>), dim3(rgrid), dim3(256), 0, st, (const R*)s->partial, dev_camera<R>(cam), part, rp, (uint32_t)n_pixels,
+                       (R*)d_lin, d_rgb8, s->stats);
     HIP_TRY(hipGetLastError());
     return MIRT_OK;
 }
@@ -192,6 +242,10 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
     mirt_scene* s = new (std::nothrow) mirt_scene();
     if (!s) return fail(MIRT_ERR_NOMEM, "out of host memory");
     s->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
+    }
     if (d->n_spheres > 0xFFFFFF00u) { delete s; return fail(MIRT_ERR_TOO_LARGE, "too many spheres"); }
     /* statics first, each section in insertion order and padded to a whole broad-phase group */
     std::vector<uint32_t> order;
@@ -237,6 +291,7 @@ void mirt_scene_destroy(mirt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (void* p : s->allocs) (void)hipFree(p);
+    if (s->partial) (void)hipFree(s->partial);
     delete s;
 }
 
@@ -261,14 +316,14 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipMemsetAsync(s->stats, 0, sizeof(DevStats), st)); /* counters and the work-queue head */
     if (stats) {
-        HIP_TRY(hipMemsetAsync(s->stats, 0, sizeof(DevStats), st));
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    rc = o->precision == MIRT_F64 ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, stats ? s->stats : nullptr, st)
-                                  : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, stats ? s->stats : nullptr, st);
+    rc = o->precision == MIRT_F64 ? launch_render<double, 2>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st)
+                                  : launch_render<float, MIRT_F32_MIN_WAVES>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st);
     if (stats) {
         if (!rc) {
             hipError_t e = hipEventRecord(e1, st);

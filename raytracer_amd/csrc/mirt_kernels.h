@@ -50,10 +50,11 @@ template <class R> struct RayT { /* core/ray.rs */
     R tm;
 };
 
+/* Per-wave LDS: one tile of (centre, r^2) records and the per-lane candidate lists (indices relative to the
+ * first sphere of the current pass, 16 bit).  f32: 1 KiB + 2 KiB per wave. */
 template <class R> struct WaveLds {
     typename Vec4<R>::type tileA[MIRT_TILE];
-    typename Vec4<R>::type tileB[MIRT_TILE];
-    uint32_t cand[MIRT_CAND_CAP][MIRT_WAVE];
+    uint16_t cand[MIRT_CAND_CAP][MIRT_WAVE];
 };
 
 template <class R> struct Closest {
@@ -97,12 +98,23 @@ __device__ inline double m_max4(double a, double b, double c, double d) { return
  * active == false do no narrow-phase work.  Returns the winner in `best` (idx == ~0u on a miss).
  *
  * Spheres are visited in groups of MIRT_GROUP (the sorted arrays are padded to whole groups with dummy
- * records, r*r = -inf, whose discriminant can never be >= 0): one batch of broadcast LDS reads, four
- * independent discriminant chains, ONE wave-level test "does any lane have a candidate in this group". */
-template <class R>
+ * records, r*r = -inf, whose discriminant can never be >= 0): one batch of wave-uniform operand fetches, four
+ * independent discriminant chains, ONE wave-level test "does any lane have a candidate in this group".
+ *
+ * Where the wave-uniform sphere data comes from (gfx9 VALU instructions take at most ONE scalar operand):
+ *   (centre0, r^2)  LDS tile, broadcast ds_read_b128 -> VGPRs      (moving spheres; statics too unless STATIC_SMEM)
+ *   (centre1-centre0) scalar loads (s_load through the scalar cache) -> SGPRs, used directly as the one scalar
+ *                   operand of v_fma_f32(tm, dc, c0): no LDS bandwidth, no VALU moves
+ *   STATIC_SMEM:    static spheres need one scalar operand per instruction only, so their records can come
+ *                   through the scalar cache as well and skip LDS altogether. */
+template <class R, bool STATIC_SMEM>
 __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t lane, bool active, const RayT<R>& ray, R tmin,
                              Closest<R>& best, uint32_t& narrow_count) {
     typedef typename Vec4<R>::type R4;
+    typedef R R4v __attribute__((ext_vector_type(4)));
+    typedef const R4v __attribute__((address_space(4))) CR4; /* constant address space: uniform index -> s_load */
+    CR4* Ac = (CR4*)sc.A;
+    CR4* Bc = (CR4*)sc.B;
     best.t = (R)INFINITY;
     best.idx = 0xFFFFFFFFu;
     best.orig = 0xFFFFFFFFu;
@@ -119,41 +131,50 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
     while (g < ngroups) { /* one pass unless some lane's candidate list fills up */
         uint32_t cnt = 0;
         bool flush = false;
+        const uint32_t pass_base = g * MIRT_GROUP;
+        uint32_t glimit = g + 0x10000u / MIRT_GROUP; /* candidate indices are 16 bit, relative to pass_base */
+        glimit = glimit < ngroups ? glimit : ngroups;
         /* ---- broad phase ---------------------------------------------------------------------- */
-        while (g < ngroups && !flush) {
+        while (g < glimit && !flush) {
             const uint32_t tile = g / groups_per_tile;
             const uint32_t base = tile * MIRT_TILE;
-            {   /* stage the tile: one coalesced 16-B (f32) record per lane */
+            if (!STATIC_SMEM || base + MIRT_TILE > sc.n_static) { /* stage the tile: one coalesced record per lane */
                 uint32_t li = base + lane;
-                uint32_t ci = li < sc.n ? li : sc.n - 1;
-                lds.tileA[lane] = sc.A[ci];
-                if (base + MIRT_TILE > sc.n_static) lds.tileB[lane] = sc.B[ci];
+                lds.tileA[lane] = sc.A[li < sc.n ? li : sc.n - 1];
             }
             uint32_t gend = (tile + 1) * groups_per_tile;
-            gend = gend < ngroups ? gend : ngroups;
+            gend = gend < glimit ? gend : glimit;
             for (; g < gend; ++g) {
-                const uint32_t j = g * MIRT_GROUP - base;
-                R4 s0 = lds.tileA[j], s1 = lds.tileA[j + 1], s2 = lds.tileA[j + 2], s3 = lds.tileA[j + 3];
-                V3<R> c0 = {s0.x, s0.y, s0.z}, c1 = {s1.x, s1.y, s1.z}, c2 = {s2.x, s2.y, s2.z}, c3 = {s3.x, s3.y, s3.z};
-                if (g >= gstatic) { /* moving: centre at the ray's time first (sphere.rs:61-70) */
-                    R4 q0 = lds.tileB[j], q1 = lds.tileB[j + 1], q2 = lds.tileB[j + 2], q3 = lds.tileB[j + 3];
-                    c0 = center_at(c0, V3<R>{q0.x, q0.y, q0.z}, tm);
-                    c1 = center_at(c1, V3<R>{q1.x, q1.y, q1.z}, tm);
-                    c2 = center_at(c2, V3<R>{q2.x, q2.y, q2.z}, tm);
-                    c3 = center_at(c3, V3<R>{q3.x, q3.y, q3.z}, tm);
-                }
+                const uint32_t i0 = g * MIRT_GROUP;
+                const uint32_t j = i0 - base;
                 R h, d0, d1, d2, d3;
-                disc(c0 - O, D, a, s0.w, h, d0);
-                disc(c1 - O, D, a, s1.w, h, d1);
-                disc(c2 - O, D, a, s2.w, h, d2);
-                disc(c3 - O, D, a, s3.w, h, d3);
+                if (g >= gstatic) { /* moving: centre at the ray's time first (sphere.rs:61-70) */
+                    R4 s0 = lds.tileA[j], s1 = lds.tileA[j + 1], s2 = lds.tileA[j + 2], s3 = lds.tileA[j + 3];
+                    R4v q0 = Bc[i0], q1 = Bc[i0 + 1], q2 = Bc[i0 + 2], q3 = Bc[i0 + 3];
+                    disc(center_at(V3<R>{s0.x, s0.y, s0.z}, V3<R>{q0.x, q0.y, q0.z}, tm) - O, D, a, s0.w, h, d0);
+                    disc(center_at(V3<R>{s1.x, s1.y, s1.z}, V3<R>{q1.x, q1.y, q1.z}, tm) - O, D, a, s1.w, h, d1);
+                    disc(center_at(V3<R>{s2.x, s2.y, s2.z}, V3<R>{q2.x, q2.y, q2.z}, tm) - O, D, a, s2.w, h, d2);
+                    disc(center_at(V3<R>{s3.x, s3.y, s3.z}, V3<R>{q3.x, q3.y, q3.z}, tm) - O, D, a, s3.w, h, d3);
+                } else if (STATIC_SMEM) {
+                    R4v s0 = Ac[i0], s1 = Ac[i0 + 1], s2 = Ac[i0 + 2], s3 = Ac[i0 + 3];
+                    disc(V3<R>{s0.x, s0.y, s0.z} - O, D, a, s0.w, h, d0);
+                    disc(V3<R>{s1.x, s1.y, s1.z} - O, D, a, s1.w, h, d1);
+                    disc(V3<R>{s2.x, s2.y, s2.z} - O, D, a, s2.w, h, d2);
+                    disc(V3<R>{s3.x, s3.y, s3.z} - O, D, a, s3.w, h, d3);
+                } else {
+                    R4 s0 = lds.tileA[j], s1 = lds.tileA[j + 1], s2 = lds.tileA[j + 2], s3 = lds.tileA[j + 3];
+                    disc(V3<R>{s0.x, s0.y, s0.z} - O, D, a, s0.w, h, d0);
+                    disc(V3<R>{s1.x, s1.y, s1.z} - O, D, a, s1.w, h, d1);
+                    disc(V3<R>{s2.x, s2.y, s2.z} - O, D, a, s2.w, h, d2);
+                    disc(V3<R>{s3.x, s3.y, s3.z} - O, D, a, s3.w, h, d3);
+                }
                 R dm = m_max4(d0, d1, d2, d3); /* fmax ignores NaN operands: NaN = miss */
                 if (__ballot(dm >= (R)0.0) != 0ull) { /* wave-uniform branch, rarely taken */
-                    const uint32_t i0 = g * MIRT_GROUP;
-                    if (d0 >= (R)0.0) { lds.cand[cnt][lane] = i0; ++cnt; }
-                    if (d1 >= (R)0.0) { lds.cand[cnt][lane] = i0 + 1; ++cnt; }
-                    if (d2 >= (R)0.0) { lds.cand[cnt][lane] = i0 + 2; ++cnt; }
-                    if (d3 >= (R)0.0) { lds.cand[cnt][lane] = i0 + 3; ++cnt; }
+                    const uint16_t r0 = (uint16_t)(i0 - pass_base);
+                    if (d0 >= (R)0.0) { lds.cand[cnt][lane] = r0; ++cnt; }
+                    if (d1 >= (R)0.0) { lds.cand[cnt][lane] = r0 + 1; ++cnt; }
+                    if (d2 >= (R)0.0) { lds.cand[cnt][lane] = r0 + 2; ++cnt; }
+                    if (d3 >= (R)0.0) { lds.cand[cnt][lane] = r0 + 3; ++cnt; }
                     if (__ballot(cnt > MIRT_CAND_CAP - MIRT_GROUP) != 0ull) { /* no room for another group */
                         flush = true;
                         ++g;
@@ -166,7 +187,7 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
         for (uint32_t k = 0; k < MIRT_CAND_CAP; ++k) {
             if (__ballot(k < cnt) == 0ull) break;
             if (k < cnt) {
-                uint32_t i = lds.cand[k][lane];
+                uint32_t i = pass_base + lds.cand[k][lane];
                 narrow_test(sc, i, ray, a_true, tmin, best);
                 ++narrow_count;
             }
@@ -348,6 +369,8 @@ __device__ inline PixelMap map_pixel(uint32_t wave_global, uint32_t lane, uint32
 
 struct DevStats { /* device-side counters, one atomic per wave at kernel end */
     unsigned long long segments, narrow, wave_iters, nan_pixels;
+    unsigned int queue_head; /* next unclaimed work item of the running render launch */
+    unsigned int _pad;
 };
 
 template <class R> __device__ inline R wave_sum_u(R v) {
@@ -355,6 +378,10 @@ template <class R> __device__ inline R wave_sum_u(R v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+#ifndef MIRT_STATIC_SMEM
+#define MIRT_STATIC_SMEM true
+#endif
 
 /* ---- K1 ------------------------------------------------------------------------------------------ */
 template <class R>
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel(DevScene<R> sc
     RayT<R> ray = primary_ray(cam, pm.lx, pm.gy);
     Closest<R> best;
     uint32_t narrow = 0;
-    trace(sc, lds, lane, pm.valid, ray, (R)0.001, best, narrow);
+    trace<R, MIRT_STATIC_SMEM>(sc, lds, lane, pm.valid, ray, (R)0.001, best, narrow);
     if (pm.valid) {
         uint32_t row = part.compact ? pm.ly : pm.gy;
         size_t o = (size_t)row * cam.W + pm.lx;
@@ -376,42 +403,104 @@ __global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel(DevScene<R> sc
     }
 }
 
-/* ---- K2 (+K3) ------------------------------------------------------------------------------------ */
-template <class R>
-__global__ __launch_bounds__(MIRT_BLOCK) void render_kernel(DevScene<R> sc, DevCamera<R> cam, DevPart part, uint32_t k0, uint32_t k1,
-                                                            R* __restrict__ out_lin, uint8_t* __restrict__ out_rgb8, DevStats* __restrict__ stats) {
+/* ---- K2: persistent waves pulling work items from a queue --------------------------------------------
+ * Work item = (pixel of this rank's band, chunk of `chunk` consecutive samples).  A LANE owns an item: it
+ * runs the item's samples one after the other (regenerating its next camera ray the moment a path ends,
+ * camera.rs:242-245), sums their radiance in sample order and stores ONE partial sum.  A WAVE reserves
+ * MIRT_QUEUE_BATCH items at a time with one atomic and deals them to its idle lanes, so lanes never wait
+ * for a slow neighbour and the grid has no tail longer than one item.  Which lane runs which item depends
+ * on timing, but an item's result does not (counter RNG keyed on pixel/sample/bounce), and K2b adds the
+ * chunks of a pixel in chunk order: the image is bit-reproducible run to run and across GPU counts. */
+#define MIRT_QUEUE_BATCH 256u
+struct RenderParams {
+    uint32_t n_items;    /* band pixels * chunks_per_pixel */
+    uint32_t chunks;     /* chunks per pixel */
+    uint32_t chunk;      /* samples per chunk */
+    uint32_t nsamples;   /* samples per pixel (1 when anti-aliasing is off) */
+    uint32_t k0, k1;     /* RNG key */
+};
+
+template <class R, int MIN_WAVES>
+__global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<R> sc, DevCamera<R> cam, DevPart part, RenderParams rp,
+                                                                        R* __restrict__ partial, DevStats* __restrict__ stats) {
     __shared__ WaveLds<R> lds_all[MIRT_WAVES_PER_BLOCK];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     WaveLds<R>& lds = lds_all[w];
-    PixelMap pm = map_pixel(blockIdx.x * MIRT_WAVES_PER_BLOCK + w, lane, cam.W, part);
-    const uint32_t pixel = pm.gy * cam.W + pm.lx; /* RNG key: independent of the partition */
     const bool aa = cam.spp > 0;
-    const uint32_t nsamples = aa ? cam.spp : 1u;
 
-    V3<R> acc = {(R)0.0, (R)0.0, (R)0.0};
-    V3<R> thr = {(R)1.0, (R)1.0, (R)1.0};
+    /* wave-uniform: the reserved range of the queue */
+    uint32_t q_next = 0, q_end = 0;
+    bool exhausted = false;
+    /* per lane */
+    bool has_work = false, need_ray = false;
+    uint32_t item = 0, pixel = 0, lx = 0, gy = 0, sample = 0, s_end = 0, depth_left = 0, bounce = 0;
+    V3<R> acc = {(R)0.0, (R)0.0, (R)0.0}, thr = {(R)1.0, (R)1.0, (R)1.0};
     RayT<R> ray = {};
-    uint32_t sample = 0, depth_left = cam.depth, bounce = 0;
     uint32_t n_seg = 0, n_narrow = 0, n_iter = 0;
-    bool running = pm.valid && cam.depth > 0; /* depth 0: color() returns black before any hit test */
-    if (!running && pm.valid) sample = nsamples;
-    if (running) {
-        Draws<R> dr{pixel, 0u, 0u, k0, k1};
-        ray = aa ? ray_for(cam, pm.lx, pm.gy, dr) : primary_ray(cam, pm.lx, pm.gy);
-    }
 
-    while (__ballot(running) != 0ull) {
+    for (;;) {
+        /* ---- deal work items to idle lanes ---------------------------------------------------------- */
+        const unsigned long long idle = __ballot(!has_work);
+        if (idle != 0ull && !(exhausted && q_next == q_end)) {
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            uint32_t got = 0xFFFFFFFFu;
+            uint32_t take = q_end - q_next;
+            take = take < n_idle ? take : n_idle;
+            if (!has_work && rank < take) got = q_next + rank;
+            q_next += take;
+            if (take < n_idle && !exhausted) { /* reserve the next batch: one atomic per wave per batch */
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&stats->queue_head, MIRT_QUEUE_BATCH);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= rp.n_items) {
+                    exhausted = true;
+                    q_next = q_end = 0;
+                } else {
+                    q_next = base;
+                    q_end = base + MIRT_QUEUE_BATCH < rp.n_items ? base + MIRT_QUEUE_BATCH : rp.n_items;
+                    uint32_t take2 = q_end - q_next;
+                    take2 = take2 < n_idle - take ? take2 : n_idle - take;
+                    if (!has_work && rank >= take && rank < take + take2) got = q_next + (rank - take);
+                    q_next += take2;
+                }
+            }
+            if (got != 0xFFFFFFFFu) {
+                item = got;
+                const uint32_t pl = got / rp.chunks, ch = got - pl * rp.chunks; /* band pixel, row-major; chunk */
+                const uint32_t ly = pl / cam.W;
+                lx = pl - ly * cam.W;
+                gy = part_global_row(part, ly);
+                pixel = gy * cam.W + lx; /* RNG key: the global pixel, independent of the partition */
+                sample = ch * rp.chunk;
+                s_end = sample + rp.chunk < rp.nsamples ? sample + rp.chunk : rp.nsamples;
+                acc = {(R)0.0, (R)0.0, (R)0.0};
+                has_work = true;
+                need_ray = true;
+            }
+        }
+        if (__ballot(has_work) == 0ull) break;
         ++n_iter;
+        /* ---- camera ray for lanes that start a sample (camera.rs:209-230 / 248-252) ------------------- */
+        if (need_ray) {
+            thr = {(R)1.0, (R)1.0, (R)1.0};
+            depth_left = cam.depth;
+            bounce = 0;
+            Draws<R> dr{pixel, sample, 0u, rp.k0, rp.k1};
+            ray = aa ? ray_for(cam, lx, gy, dr) : primary_ray(cam, lx, gy);
+            need_ray = false;
+        }
+        /* ---- one ray segment for every lane of the wave ---------------------------------------------- */
         Closest<R> best;
-        trace(sc, lds, lane, running, ray, (R)0.001, best, n_narrow);
-        if (running) {
+        trace<R, MIRT_STATIC_SMEM>(sc, lds, lane, has_work, ray, (R)0.001, best, n_narrow);
+        if (has_work) {
             ++n_seg;
             bool done;
             V3<R> radiance = {(R)0.0, (R)0.0, (R)0.0};
             if (best.idx != 0xFFFFFFFFu) {
                 Hit<R> hit = make_hit(sc, best, ray);
                 ++bounce;
-                Draws<R> dr{pixel, sample, bounce, k0, k1};
+                Draws<R> dr{pixel, sample, bounce, rp.k0, rp.k1};
                 V3<R> att;
                 RayT<R> nxt;
                 if (scatter(sc, sc.material[best.idx], ray, hit, dr, att, nxt)) {
@@ -420,7 +509,7 @@ __global__ __launch_bounds__(MIRT_BLOCK) void render_kernel(DevScene<R> sc, DevC
                     --depth_left;
                     done = depth_left == 0; /* color(.., 0) = black */
                 } else {
-                    done = true;
+                    done = true; /* absorbed: black for the whole path (camera.rs:279) */
                 }
             } else { /* sky: camera.rs:282-284 */
                 V3<R> ud = unit(ray.d);
@@ -432,45 +521,53 @@ __global__ __launch_bounds__(MIRT_BLOCK) void render_kernel(DevScene<R> sc, DevC
             if (done) {
                 acc = acc + radiance;
                 ++sample;
-                if (sample < nsamples) { /* regenerate: this lane starts its next sample at once */
-                    thr = {(R)1.0, (R)1.0, (R)1.0};
-                    depth_left = cam.depth;
-                    bounce = 0;
-                    Draws<R> dr{pixel, sample, 0u, k0, k1};
-                    ray = ray_for(cam, pm.lx, pm.gy, dr);
+                if (sample < s_end) {
+                    need_ray = true; /* regenerate: this lane starts its next sample in the next iteration */
                 } else {
-                    running = false;
+                    size_t o = (size_t)item * 3;
+                    partial[o] = acc.x;
+                    partial[o + 1] = acc.y;
+                    partial[o + 2] = acc.z;
+                    has_work = false;
                 }
             }
         }
     }
+    uint32_t s1 = wave_sum_u(n_seg), s2 = wave_sum_u(n_narrow);
+    if (lane == 0) {
+        atomicAdd(&stats->segments, (unsigned long long)s1);
+        atomicAdd(&stats->narrow, (unsigned long long)s2);
+        atomicAdd(&stats->wave_iters, (unsigned long long)n_iter);
+    }
+}
 
+/* ---- K2b (+K3): add the chunks of a pixel in chunk order, scale by 1/spp (camera.rs:246), gamma + quantise
+ *      (rgb.rs:20-36).  One thread per band pixel. */
+template <class R>
+__global__ void resolve_kernel(const R* __restrict__ partial, DevCamera<R> cam, DevPart part, RenderParams rp, uint32_t n_pixels,
+                               R* __restrict__ out_lin, uint8_t* __restrict__ out_rgb8, DevStats* __restrict__ stats) {
+    uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pl >= n_pixels) return;
+    V3<R> acc = {(R)0.0, (R)0.0, (R)0.0};
+    const R* p = partial + (size_t)pl * rp.chunks * 3;
+    for (uint32_t c = 0; c < rp.chunks; ++c) acc = acc + V3<R>{p[3 * c], p[3 * c + 1], p[3 * c + 2]};
+    if (cam.spp > 0) acc = acc * ((R)1.0 / (R)cam.spp); /* samples_scale, camera.rs:50,246 */
+    uint32_t ly = pl / cam.W, lx = pl - ly * cam.W;
+    uint32_t row = part.compact ? ly : part_global_row(part, ly);
+    size_t o = ((size_t)row * cam.W + lx) * 3;
+    if (out_lin) {
+        out_lin[o] = acc.x;
+        out_lin[o + 1] = acc.y;
+        out_lin[o + 2] = acc.z;
+    }
     uint32_t nan = 0;
-    if (pm.valid) {
-        if (aa) acc = acc * ((R)1.0 / (R)cam.spp); /* samples_scale, camera.rs:50,246 */
-        uint32_t row = part.compact ? pm.ly : pm.gy;
-        size_t o = ((size_t)row * cam.W + pm.lx) * 3;
-        if (out_lin) {
-            out_lin[o] = acc.x;
-            out_lin[o + 1] = acc.y;
-            out_lin[o + 2] = acc.z;
-        }
-        uint32_t r = quantize1(acc.x, nan), g = quantize1(acc.y, nan), b = quantize1(acc.z, nan);
-        if (out_rgb8) {
-            out_rgb8[o] = (uint8_t)r;
-            out_rgb8[o + 1] = (uint8_t)g;
-            out_rgb8[o + 2] = (uint8_t)b;
-        }
+    uint32_t r = quantize1(acc.x, nan), g = quantize1(acc.y, nan), b = quantize1(acc.z, nan);
+    if (out_rgb8) {
+        out_rgb8[o] = (uint8_t)r;
+        out_rgb8[o + 1] = (uint8_t)g;
+        out_rgb8[o + 2] = (uint8_t)b;
     }
-    if (stats) {
-        uint32_t s1 = wave_sum_u(n_seg), s2 = wave_sum_u(n_narrow), s3 = wave_sum_u(nan);
-        if (lane == 0) {
-            atomicAdd(&stats->segments, (unsigned long long)s1);
-            atomicAdd(&stats->narrow, (unsigned long long)s2);
-            atomicAdd(&stats->wave_iters, (unsigned long long)n_iter);
-            if (s3) atomicAdd(&stats->nan_pixels, (unsigned long long)s3);
-        }
-    }
+    if (nan && stats) atomicAdd(&stats->nan_pixels, 1ull);
 }
 
 /* ---- K3 ------------------------------------------------------------------------------------------ */
