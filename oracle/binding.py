@@ -38,8 +38,8 @@ def load():
     lib.oracle_aabb_slab.argtypes = [P(dbl), P(dbl), P(dbl), P(dbl), C.c_int, dbl, dbl]
     lib.oracle_scatter.argtypes = [P(abi.MirtSceneDesc), u32, P(dbl), P(dbl), dbl, P(dbl), u64, u32, u32, u32, P(dbl)]
     lib.oracle_texture_color.argtypes = [P(abi.MirtSceneDesc), u32, dbl, dbl, P(dbl), P(dbl)]
-    lib.oracle_draws.argtypes = [u64, u32, u32, u32, u32, u32, P(dbl)]
-    lib.oracle_draws.restype = None
+    lib.oracle_draw_dim.argtypes = [u64, u32, u32, u32, u32, u32]
+    lib.oracle_draw_dim.restype = dbl
     _lib = lib
     return lib
 
@@ -103,10 +103,14 @@ def philox(ctr, key):
     return list(o)
 
 
+def draw_dim(seed, pixel, sample, bounce, dim, precision=abi.F64):
+    """Dimension `dim` of the RNG stream (seed; pixel, sample, bounce) as the contract defines it for `precision`."""
+    return load().oracle_draw_dim(seed, pixel, sample, bounce, dim, precision)
+
+
 def draws(seed, pixel, sample, bounce, blk, precision=abi.F64):
-    o = (C.c_double * 2)()
-    load().oracle_draws(seed, pixel, sample, bounce, blk, precision, o)
-    return o[0], o[1]
+    """f64 helper kept for the tests: the two uniforms of Philox block `blk` = dims 2*blk and 2*blk+1."""
+    return draw_dim(seed, pixel, sample, bounce, 2 * blk, precision), draw_dim(seed, pixel, sample, bounce, 2 * blk + 1, precision)
 
 
 def sphere_hit(sphere: abi.MirtSphere, o, d, tm=0.0, tmin=0.001, tmax=float("inf")):

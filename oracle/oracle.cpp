@@ -58,27 +58,33 @@ static inline void philox4x32_10(const uint32_t c_in[4], const uint32_t k_in[2],
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-template <class R> struct Uni;
-template <> struct Uni<double> {
-    /* rand 0.9 StandardUniform for f64: 53 random bits * 2^-53 in [0,1). */
-    static double u01(uint64_t u) { return (double)(u >> 11) * 0x1.0p-53; }
-};
-template <> struct Uni<float> {
-    /* top 24 bits of the same 64-bit word: the f32 draw is the f64 draw truncated. */
-    static float u01(uint64_t u) { return (float)(uint32_t)(u >> 40) * 0x1.0p-24f; }
-};
-
-/* Two uniforms per Philox block.  ctr = (pixel, sample, bounce, block), key = seed. */
-template <class R> struct Draws {
+/* RNG contract: dimension d of the stream (pixel, sample, bounce) - Philox counter (pixel, sample, bounce, block).
+ *   f64: block = d / 2, 64-bit word pair d % 2 (x0|x1<<32 or x2|x3<<32), u = (word >> 11) * 2^-53
+ *        (rand 0.9's StandardUniform for f64: 53 random bits in [0,1))
+ *   f32: block = d / 4, 32-bit word d % 4,                              u = (word >> 8) * 2^-24
+ * Blocks are computed lazily so that a draw the reference short-circuits away costs nothing here either. */
+template <class R> struct Draws;
+template <> struct Draws<double> {
     uint32_t pixel, sample, bounce;
     uint64_t seed;
-    void block(uint32_t blk, R& a, R& b) const {
-        uint32_t c[4] = {pixel, sample, bounce, blk};
+    double dim(uint32_t d) const {
+        uint32_t c[4] = {pixel, sample, bounce, d / 2};
         uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
         uint32_t o[4];
         philox4x32_10(c, k, o);
-        a = Uni<R>::u01((uint64_t)o[0] | ((uint64_t)o[1] << 32));
-        b = Uni<R>::u01((uint64_t)o[2] | ((uint64_t)o[3] << 32));
+        uint64_t u = (d % 2) ? ((uint64_t)o[2] | ((uint64_t)o[3] << 32)) : ((uint64_t)o[0] | ((uint64_t)o[1] << 32));
+        return (double)(u >> 11) * 0x1.0p-53;
+    }
+};
+template <> struct Draws<float> {
+    uint32_t pixel, sample, bounce;
+    uint64_t seed;
+    float dim(uint32_t d) const {
+        uint32_t c[4] = {pixel, sample, bounce, d / 4};
+        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+        uint32_t o[4];
+        philox4x32_10(c, k, o);
+        return (float)(o[d % 4] >> 8) * 0x1.0p-24f;
     }
 };
 
@@ -458,17 +464,16 @@ template <class R> static inline V3<R> refract(V3<R> uv, V3<R> n, R e) { /* mate
 /* point3.rs:88-93: three U[0,1) draws -> positive octant only, then normalise (reference quirk). */
 template <class R> static inline V3<R> random_unit_on_sphere(R x, R y, R z) { return unit(V3<R>{x, y, z}); }
 
-/* RNG contract at bounce b (ctr.z = b >= 1): block 0 -> (ua, ub), block 1 -> (uc, ud).
- *   Lambertian: test = ua, vector = (ub, uc, ud).  Metal: vector = (ua, ub, uc).  Dielectric: ua. */
+/* RNG contract at bounce b (ctr.z = b >= 1), dimensions 0..3:
+ *   Lambertian: test = dim 0, vector = dims (1, 2, 3).  Metal: vector = dims (0, 1, 2).  Dielectric: dim 0. */
 template <class R>
 static inline bool scatter(const Scene<R>& sc, const Material<R>& m, const Ray<R>& rin, const HitRec<R>& hr, const Draws<R>& dr,
                            V3<R>& att, Ray<R>& out) {
     switch (m.kind) {
     case MIRT_MAT_LAMBERTIAN: { /* material.rs:59-84 */
-        R ua, ub, uc, ud;
-        dr.block(0, ua, ub);
+        R ua = dr.dim(0);
         if (ua < m.reflectance) {
-            dr.block(1, uc, ud);
+            R ub = dr.dim(1), uc = dr.dim(2), ud = dr.dim(3);
             V3<R> dir = hr.n + random_unit_on_sphere(ub, uc, ud);
             if (near_zero(dir)) dir = hr.n;
             out = {hr.p, dir, rin.tm};
@@ -480,9 +485,7 @@ static inline bool scatter(const Scene<R>& sc, const Material<R>& m, const Ray<R
     case MIRT_MAT_METAL: { /* material.rs:97-114 */
         V3<R> refl = reflect(rin.d, hr.n);
         if (m.has_fuzz) {
-            R ua, ub, uc, ud;
-            dr.block(0, ua, ub);
-            dr.block(1, uc, ud);
+            R ua = dr.dim(0), ub = dr.dim(1), uc = dr.dim(2);
             refl = unit(refl) + random_unit_on_sphere(ua, ub, uc) * m.fuzz;
         }
         out = {hr.p, refl, rin.tm};
@@ -497,8 +500,7 @@ static inline bool scatter(const Scene<R>& sc, const Material<R>& m, const Ray<R
         R sin_theta = std::sqrt((R)1.0 - cos_theta * cos_theta);
         bool refl = ri * sin_theta > (R)1.0;
         if (!refl) { /* `||` short-circuits: the draw happens only when not total internal reflection */
-            R ua, ub;
-            dr.block(0, ua, ub);
+            R ua = dr.dim(0);
             refl = schlick(cos_theta, ri) > ua;
         }
         V3<R> dir = refl ? reflect(ud, hr.n) : refract(ud, hr.n, ri);
@@ -541,25 +543,21 @@ static V3<R> color(const Scene<R>& sc, const Ray<R>& ray, uint32_t depth, Draws<
     return {(R)1.0 * ((R)1.0 - a) + (R)0.5 * a, (R)1.0 * ((R)1.0 - a) + (R)0.7 * a, (R)1.0 * ((R)1.0 - a) + (R)1.0 * a};
 }
 
-/* camera.rs:209-230 with the RNG contract: bounce 0, block 0 -> AA (w,h), block 1 -> disk (r,theta),
- * block 2 -> (time, unused). */
+/* camera.rs:209-230 with the RNG contract: bounce 0, dims 0,1 -> AA (w,h), dims 2,3 -> disk (r,theta), dim 4 -> time. */
 template <class R> static inline Ray<R> ray_for(const Cam<R>& c, uint32_t wn, uint32_t hn, const Draws<R>& dr) {
-    R ua, ub;
-    dr.block(0, ua, ub);
+    R ua = dr.dim(0), ub = dr.dim(1);
     R ox = ua - (R)0.5, oy = ub - (R)0.5; /* Uniform(-0.5, 0.5) */
     V3<R> px = c.px00 + (c.du * ((R)wn + ox)) + (c.dv * ((R)hn + oy));
     V3<R> orig = c.lookfrom;
     if (!(c.defocus_angle <= (R)0.0)) { /* camera.rs:220-224, 261-264; point3.rs:106-110 */
-        R uc, ud;
-        dr.block(1, uc, ud);
+        R uc = dr.dim(2), ud = dr.dim(3);
         const R TAU = (R)6.28318530717958647692528676655900577;
         R r = std::sqrt(uc);
         R th = ud * TAU;
         R dx = r * std::cos(th), dy = r * std::sin(th);
         orig = c.lookfrom + (c.disk_u * dx) + (c.disk_v * dy);
     }
-    R ue, uf;
-    dr.block(2, ue, uf);
+    R ue = dr.dim(4);
     return {orig, px - orig, ue};
 }
 template <class R> static inline Ray<R> primary_ray(const Cam<R>& c, uint32_t wn, uint32_t hn) { /* camera.rs:248-252 */
@@ -796,19 +794,10 @@ int oracle_texture_color(const mirt_scene_desc* d, uint32_t texture, double u, d
     return 0;
 }
 
-/* Uniform draws of the contract, for tests: out[0..1] = the two uniforms of block `blk`. */
-void oracle_draws(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t blk, uint32_t precision, double* out) {
-    if (precision == 64) {
-        orc::Draws<double> dr{pixel, sample, bounce, seed};
-        double a, b;
-        dr.block(blk, a, b);
-        out[0] = a; out[1] = b;
-    } else {
-        orc::Draws<float> dr{pixel, sample, bounce, seed};
-        float a, b;
-        dr.block(blk, a, b);
-        out[0] = a; out[1] = b;
-    }
+/* One uniform of the contract, for tests: dimension `dim` of (seed; pixel, sample, bounce). */
+double oracle_draw_dim(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t dim, uint32_t precision) {
+    if (precision == 64) return orc::Draws<double>{pixel, sample, bounce, seed}.dim(dim);
+    return (double)orc::Draws<float>{pixel, sample, bounce, seed}.dim(dim);
 }
 
 } /* extern "C" */

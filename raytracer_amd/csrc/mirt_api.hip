@@ -17,7 +17,7 @@
 using namespace mirt;
 
 #ifndef MIRT_F32_MIN_WAVES
-#define MIRT_F32_MIN_WAVES 6 /* __launch_bounds__ waves per SIMD for the f32 render kernel (A/B on MI355X: 6 beats 4 and 8) */
+#define MIRT_F32_MIN_WAVES 4 /* __launch_bounds__ waves per SIMD for the f32 render kernel (A/B on MI355X, profiles/r01_*ab*) */
 #endif
 
 static thread_local std::string g_err;

@@ -121,8 +121,10 @@ __host__ __device__ inline uint32_t part_global_row(const DevPart& p, uint32_t l
 }
 
 /* ---- counter-based RNG: Philox4x32-10 (Salmon et al., SC'11) --------------------------------------
- * ctr = (pixel, sample, bounce, block), key = (seed_lo, seed_hi).  Each block yields two uniforms:
- * word pairs (x0|x1<<32) and (x2|x3<<32); f64 draw = (u64>>11)*2^-53, f32 draw = (u64>>40)*2^-24. */
+ * ctr = (pixel, sample, bounce, block), key = (seed_lo, seed_hi).  Dimension d of a stream (pixel, sample, bounce):
+ *   f64: block d/2, 64-bit word pair d%2 (x0|x1<<32, x2|x3<<32), u = (word >> 11) * 2^-53
+ *   f32: block d/4, 32-bit word d%4,                             u = (word >> 8)  * 2^-24
+ * (Philox's integer multiplies are quarter-rate on the VALU: the f32 mode gets four draws out of one block.) */
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -141,19 +143,34 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-__device__ inline double u01_from(uint32_t lo, uint32_t hi, double) {
-    uint64_t u = (uint64_t)lo | ((uint64_t)hi << 32);
-    return (double)(u >> 11) * 0x1.0p-53;
-}
-__device__ inline float u01_from(uint32_t, uint32_t hi, float) { return (float)(hi >> 8) * 0x1.0p-24f; }
 
-template <class R> struct Draws {
+template <class R> struct Draws;
+template <> struct Draws<double> {
     uint32_t pixel, sample, bounce, k0, k1;
-    __device__ inline void block(uint32_t blk, R& a, R& b) const {
+    /* dims 2*blk and 2*blk+1 */
+    __device__ inline void pair(uint32_t blk, double& a, double& b) const {
         uint32_t o[4];
         philox4x32_10(pixel, sample, bounce, blk, k0, k1, o);
-        a = u01_from(o[0], o[1], (R)0);
-        b = u01_from(o[2], o[3], (R)0);
+        a = (double)(((uint64_t)o[0] | ((uint64_t)o[1] << 32)) >> 11) * 0x1.0p-53;
+        b = (double)(((uint64_t)o[2] | ((uint64_t)o[3] << 32)) >> 11) * 0x1.0p-53;
+    }
+    __device__ inline void dims0123(double& a, double& b, double& c, double& d) const { pair(0, a, b); pair(1, c, d); }
+    __device__ inline double dim0() const { double a, b; pair(0, a, b); return a; }
+    __device__ inline double dim4() const { double a, b; pair(2, a, b); return a; }
+};
+template <> struct Draws<float> {
+    uint32_t pixel, sample, bounce, k0, k1;
+    __device__ static inline float cvt(uint32_t w) { return (float)(w >> 8) * 0x1.0p-24f; }
+    __device__ inline void dims0123(float& a, float& b, float& c, float& d) const {
+        uint32_t o[4];
+        philox4x32_10(pixel, sample, bounce, 0u, k0, k1, o);
+        a = cvt(o[0]); b = cvt(o[1]); c = cvt(o[2]); d = cvt(o[3]);
+    }
+    __device__ inline float dim0() const { float a, b, c, d; dims0123(a, b, c, d); return a; }
+    __device__ inline float dim4() const {
+        uint32_t o[4];
+        philox4x32_10(pixel, sample, bounce, 1u, k0, k1, o);
+        return cvt(o[0]);
     }
 };
 

@@ -29,16 +29,23 @@ namespace mirt {
 __device__ inline double ray_a(V3<double> d) { return dot(d, d); }
 __device__ inline float ray_a(V3<float> d) { return __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x)); }
 
-__device__ inline void disc(V3<double> oc, V3<double> D, double a, double r2, double& h, double& d) {
+__device__ inline void disc(V3<double> oc, V3<double> D, double a, double r2, double& h, double& d, double& c) {
     h = dot(D, oc);
-    double c = dot(oc, oc) - r2;
+    c = dot(oc, oc) - r2;
     d = h * h - a * c;
 }
-__device__ inline void disc(V3<float> oc, V3<float> D, float a, float r2, float& h, float& d) {
+__device__ inline void disc(V3<float> oc, V3<float> D, float a, float r2, float& h, float& d, float& c) {
     h = __builtin_fmaf(D.z, oc.z, __builtin_fmaf(D.y, oc.y, D.x * oc.x));
-    float c = __builtin_fmaf(oc.x, oc.x, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.z, oc.z, -r2)));
+    c = __builtin_fmaf(oc.x, oc.x, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.z, oc.z, -r2)));
     d = __builtin_fmaf(h, h, -(a * c));
 }
+template <class R> __device__ inline void disc(V3<R> oc, V3<R> D, R a, R r2, R& h, R& d) {
+    R c;
+    disc(oc, D, a, r2, h, d, c);
+}
+/* |h| below which h*h may be subnormal (the behind-the-ray shortcut of narrow_test needs h*h normal) */
+__device__ inline float h_normal_min(float) { return 1e-18f; }
+__device__ inline double h_normal_min(double) { return 1e-150; }
 /* sphere.rs:61-70 */
 __device__ inline V3<double> center_at(V3<double> c0, V3<double> dc, double tm) { return {c0.x + tm * dc.x, c0.y + tm * dc.y, c0.z + tm * dc.z}; }
 __device__ inline V3<float> center_at(V3<float> c0, V3<float> dc, float tm) {
@@ -73,9 +80,13 @@ __device__ inline void narrow_test(const DevScene<R>& sc, uint32_t i, const RayT
         C = center_at(C, V3<R>{sb.x, sb.y, sb.z}, ray.tm);
     }
     V3<R> oc = C - ray.o;
-    R h, d;
-    disc(oc, ray.d, a, sa.w, h, d);
+    R h, d, c;
+    disc(oc, ray.d, a, sa.w, h, d, c);
     if (!(d >= (R)0.0)) return;
+    /* Sphere entirely behind the ray (h < 0, origin outside): d = rn(h*h - a*c) <= rn(h*h), and sqrt(rn(h*h)) == |h|
+     * exactly when h*h is normal, so sqrt(d) <= -h: both roots (h -+ sqrt(d))/a are <= 0 < tmin.  Exact shortcut: it
+     * rejects only what the root test below would reject, before paying for the sqrt and the two divisions. */
+    if (h < -h_normal_min(h) && c > (R)0.0 && tmin >= (R)0.0) return;
     uint32_t orig = sc.orig_id[i];
     R sq = m_sqrt(d);
     R t = (h - sq) / a;
@@ -276,10 +287,9 @@ __device__ inline bool scatter(const DevScene<R>& sc, uint32_t mat, const RayT<R
                                RayT<R>& out) {
     const DevMaterial<R>& m = sc.mats[mat];
     if (m.kind == MIRT_MAT_LAMBERTIAN) { /* material.rs:59-84 */
-        R ua, ub, uc, ud;
-        dr.block(0, ua, ub);
+        R ua, ub, uc, ud; /* dims: 0 = absorb test, 1..3 = vector */
+        dr.dims0123(ua, ub, uc, ud);
         if (!(ua < m.reflectance)) return false;
-        dr.block(1, uc, ud);
         V3<R> dir = hit.n + unit(V3<R>{ub, uc, ud}); /* positive-octant quirk of point3.rs:88-93 */
         const R e = (R)1e-8;
         if (m_fabs(dir.x) < e && m_fabs(dir.y) < e && m_fabs(dir.z) < e) dir = hit.n;
@@ -290,9 +300,8 @@ __device__ inline bool scatter(const DevScene<R>& sc, uint32_t mat, const RayT<R
     if (m.kind == MIRT_MAT_METAL) { /* material.rs:97-114 */
         V3<R> refl = reflect(rin.d, hit.n);
         if (m.has_fuzz) {
-            R ua, ub, uc, ud;
-            dr.block(0, ua, ub);
-            dr.block(1, uc, ud);
+            R ua, ub, uc, ud; /* dims 0..2 = vector */
+            dr.dims0123(ua, ub, uc, ud);
             refl = unit(refl) + unit(V3<R>{ua, ub, uc}) * m.fuzz;
         }
         out = {hit.p, refl, rin.tm};
@@ -307,9 +316,7 @@ __device__ inline bool scatter(const DevScene<R>& sc, uint32_t mat, const RayT<R
     R sin_theta = m_sqrt((R)1.0 - cos_theta * cos_theta);
     bool refl = ri * sin_theta > (R)1.0;
     if (!refl) {
-        R ua, ub;
-        dr.block(0, ua, ub);
-        refl = schlick(cos_theta, ri) > ua;
+        refl = schlick(cos_theta, ri) > dr.dim0();
     }
     V3<R> dir = refl ? reflect(ud, hit.n) : refract(ud, hit.n, ri);
     out = {hit.p, dir, rin.tm};
@@ -318,23 +325,19 @@ __device__ inline bool scatter(const DevScene<R>& sc, uint32_t mat, const RayT<R
 
 /* ---- camera rays: camera/camera.rs:209-230, 248-252, 261-264 --------------------------------------- */
 template <class R> __device__ inline RayT<R> ray_for(const DevCamera<R>& c, uint32_t wn, uint32_t hn, const Draws<R>& dr) {
-    R ua, ub;
-    dr.block(0, ua, ub);
+    R ua, ub, uc, ud; /* dims 0,1 = anti-aliasing offsets, 2,3 = lens disk (r, theta), 4 = shutter time */
+    dr.dims0123(ua, ub, uc, ud);
     R ox = ua - (R)0.5, oy = ub - (R)0.5;
     V3<R> px = c.px00 + (c.du * ((R)wn + ox)) + (c.dv * ((R)hn + oy));
     V3<R> orig = c.lookfrom;
     if (!(c.defocus_angle <= (R)0.0)) {
-        R uc, ud;
-        dr.block(1, uc, ud);
         const R TAU = (R)6.28318530717958647692528676655900577;
         R r = m_sqrt(uc);
         R th = ud * TAU;
         R dx = r * m_cos(th), dy = r * m_sin(th);
         orig = c.lookfrom + (c.disk_u * dx) + (c.disk_v * dy);
     }
-    R ue, uf;
-    dr.block(2, ue, uf);
-    return {orig, px - orig, ue};
+    return {orig, px - orig, dr.dim4()};
 }
 template <class R> __device__ inline RayT<R> primary_ray(const DevCamera<R>& c, uint32_t wn, uint32_t hn) {
     V3<R> pc = c.ul + (c.du * (R)wn) + (c.dv * (R)hn);

@@ -24,15 +24,15 @@ def test_philox_kat(oracle, ctr, key, want):
 
 
 def test_draw_contract(oracle):
-    # f64 draw = (u64 >> 11) * 2^-53 of word pairs; the f32 draw is the same word truncated to 24 bits
-    o = oracle.philox([5, 6, 7, 1], [9, 0])
-    a64, b64 = oracle.draws(9, 5, 6, 7, 1, abi.F64)
-    a32, b32 = oracle.draws(9, 5, 6, 7, 1, abi.F32)
-    u0 = o[0] | (o[1] << 32)
-    u1 = o[2] | (o[3] << 32)
-    assert a64 == (u0 >> 11) * 2.0**-53 and b64 == (u1 >> 11) * 2.0**-53
-    assert a32 == (u0 >> 40) * 2.0**-24 and b32 == (u1 >> 40) * 2.0**-24
-    assert 0.0 <= a64 < 1.0 and 0.0 <= a32 < 1.0
+    # f64: dim d = 64-bit word pair d%2 of block d/2, (u64 >> 11) * 2^-53;  f32: dim d = 32-bit word d%4 of block d/4, >> 8
+    for d in range(6):
+        o = oracle.philox([5, 6, 7, d // 2], [9, 0])
+        u = (o[0] | (o[1] << 32)) if d % 2 == 0 else (o[2] | (o[3] << 32))
+        assert oracle.draw_dim(9, 5, 6, 7, d, abi.F64) == (u >> 11) * 2.0**-53
+        o = oracle.philox([5, 6, 7, d // 4], [9, 0])
+        assert oracle.draw_dim(9, 5, 6, 7, d, abi.F32) == (o[d % 4] >> 8) * 2.0**-24
+    vals = [oracle.draw_dim(3, 1, s, 0, d, p) for s in range(50) for d in range(5) for p in (abi.F64, abi.F32)]
+    assert all(0.0 <= v < 1.0 for v in vals) and 0.4 < sum(vals) / len(vals) < 0.6
 
 
 # ---- the reference's only unit test: src/scene/aabb.rs:123-137 ---------------------------------------------------

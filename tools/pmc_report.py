@@ -1,0 +1,19 @@
+import csv, glob, sys
+tag = sys.argv[1]
+vals = {}
+ms = None
+for f in sorted(glob.glob(f"gpurun_out/pmc_{tag}_*/p_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "render_kernel" in r["Kernel_Name"]:
+            vals[r["Counter_Name"]] = float(r["Counter_Value"])
+            ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            meta = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"], r["Scratch_Size"])
+print(f"render_kernel {ms:.2f} ms grid/wg/lds/vgpr/sgpr/scratch = {meta}")
+for k in sorted(vals):
+    print(f"{k:30s} {vals[k]:.6g}")
+g = vals.get
+if g("GRBM_GUI_ACTIVE") and g("SQ_INSTS_VALU"):
+    cyc = g("GRBM_GUI_ACTIVE") / 8.0
+    print(f"clock ~ {cyc/ms/1e6:.2f} GHz; VALU wave-instructions per SIMD-cycle = {g('SQ_INSTS_VALU')/(cyc*1024):.3f} (peak 0.5)")
+    if g("SQ_WAVE_CYCLES"):
+        print(f"avg waves resident per SIMD = {g('SQ_WAVE_CYCLES')*4/(cyc*1024):.2f}")
