@@ -44,6 +44,7 @@ struct mirt_scene {
     SceneBuffers<float> f32;
     SceneBuffers<double> f64;
     uint32_t *orig_id = nullptr, *material = nullptr, *texels = nullptr;
+    float4* S = nullptr; /* f32 conservative broad-phase records */
     DevImage* imgs = nullptr;
     DevStats* stats = nullptr; /* one per scene: calls on one scene handle are not re-entrant */
     std::vector<void*> allocs;
@@ -104,6 +105,8 @@ template <class R> static DevScene<R> dev_scene(const mirt_scene* s, const Scene
     DevScene<R> d;
     d.A = b.A; d.B = b.B; d.orig_id = s->orig_id; d.material = s->material; d.mats = b.mats; d.texs = b.texs;
     d.imgs = s->imgs; d.texels = s->texels; d.n = s->n; d.n_static = s->n_static;
+    d.S = sizeof(R) == 4 ? s->S : nullptr;
+    d.dbg = s->stats ? &s->stats->broad_misses : nullptr;
     return d;
 }
 template <class R> static DevCamera<R> dev_camera(const mirt_camera* c) {
@@ -280,6 +283,36 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
         mirt_scene_destroy(s);
         return rc;
     }
+    {   /* conservative bounding records of trace_cons, from the f32 values the kernels see, in double */
+        std::vector<float4> S(order.size());
+        const double eps = 1.0 / 16777216.0; /* 2^-24 */
+        for (size_t k = 0; k < order.size(); ++k) {
+            if (order[k] == 0xFFFFFFFFu) { S[k].x = S[k].y = S[k].z = 0.f; S[k].w = INFINITY; continue; }
+            const mirt_sphere& sp = d->spheres[order[k]];
+            double c0[3], dc[3] = {0, 0, 0};
+            for (int a = 0; a < 3; ++a) {
+                float f0 = (float)sp.center0[a], f1 = (float)sp.center1[a];
+                c0[a] = f0;
+                if (sp.moving) dc[a] = (double)(f1 - f0); /* the f32 difference the kernel uses */
+            }
+            float rf = (float)sp.radius;
+            double r = rf > 0.f ? rf : 0.0;
+            float Mf[3];
+            double M2 = 0, dcl = 0;
+            for (int a = 0; a < 3; ++a) { Mf[a] = (float)(c0[a] + 0.5 * dc[a]); dcl += dc[a] * dc[a]; }
+            dcl = std::sqrt(dcl);
+            double Ml = std::sqrt((double)Mf[0] * Mf[0] + (double)Mf[1] * Mf[1] + (double)Mf[2] * Mf[2]);
+            M2 = Ml * Ml;
+            /* ball radius: sphere + half the travel + rounding of M, of fma(tm, dc, c0) and of the travel itself */
+            double rho = r + 0.5 * dcl + 8.0 * eps * (Ml + dcl + r);
+            double w = M2 - rho * rho - 160.0 * eps * (M2 + rho * rho);
+            float wf = (float)w;
+            if ((double)wf > w) wf = std::nextafterf(wf, -INFINITY); /* round toward the conservative side */
+            wf = std::nextafterf(wf, -INFINITY);
+            S[k].x = Mf[0]; S[k].y = Mf[1]; S[k].z = Mf[2]; S[k].w = wf;
+        }
+        if ((rc = upload(s, S, &s->S))) { mirt_scene_destroy(s); return rc; }
+    }
     std::vector<DevStats> st(1);
     memset(st.data(), 0, sizeof(DevStats));
     if ((rc = upload(s, st, &s->stats))) { mirt_scene_destroy(s); return rc; }
@@ -343,6 +376,19 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
             stats->wave_iterations = h.wave_iters;
             stats->nan_pixels = h.nan_pixels;
             stats->kernel_ms = ms;
+#ifdef MIRT_VERIFY_BROAD
+            fprintf(stderr, "[mirt verify broad] exact candidates missed by the conservative broad phase: %llu\n", h.broad_misses);
+#endif
+#ifdef MIRT_PHASE_TIMING
+            {
+                static const char* names[6] = {"queue", "raygen", "broad", "narrow", "shade", "other"};
+                unsigned long long tot = 0;
+                for (int i = 0; i < 6; ++i) tot += h.phase_cycles[i];
+                fprintf(stderr, "[mirt phase timing] wave-cycles:");
+                for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h.phase_cycles[i] / (double)(tot ? tot : 1));
+                fprintf(stderr, "  (total %.3g cycles, %.0f per wave-iteration)\n", (double)tot, (double)tot / (double)(h.wave_iters ? h.wave_iters : 1));
+            }
+#endif
         }
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);

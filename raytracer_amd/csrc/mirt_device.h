@@ -92,6 +92,11 @@ template <class R> struct DevScene {
     const DevTexture<R>* texs;
     const DevImage* imgs;
     const uint32_t* texels;          /* RGBA8 pool                              */
+    /* f32 only: conservative bounding record per sorted sphere for the broad phase, (M.x, M.y, M.z, w):
+     * M = centre of the ball that contains the sphere over the whole shutter interval, w = |M|^2 - rho^2 - margin
+     * (see trace_cons).  NULL in the f64 instantiation, whose broad phase evaluates the exact discriminant. */
+    const float4* S;
+    unsigned long long* dbg;         /* diagnostic builds: counter of broad-phase misses (must stay 0) */
     uint32_t n, n_static;
 };
 template <class R> struct DevCamera { /* struct Camera, camera/camera.rs:107-120, rounded once to Real */

@@ -102,6 +102,20 @@ __device__ inline void narrow_test(const DevScene<R>& sc, uint32_t i, const RayT
     }
 }
 
+/* Diagnostic build only (-DMIRT_PHASE_TIMING): per-wave cycle stamps (s_memtime) around the phases of the segment
+ * loop, summed into DevStats::phase_cycles.  The product build compiles this to nothing. */
+struct PhaseTimer {
+#ifdef MIRT_PHASE_TIMING
+    unsigned long long last, acc[6];
+    __device__ inline void start() { last = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 6; ++i) acc[i] = 0; }
+    __device__ inline void stamp(int i) { unsigned long long now = __builtin_amdgcn_s_memtime(); acc[i] += now - last; last = now; }
+#else
+    __device__ inline void start() {}
+    __device__ inline void stamp(int) {}
+#endif
+};
+enum { PH_QUEUE = 0, PH_RAYGEN = 1, PH_BROAD = 2, PH_NARROW = 3, PH_SHADE = 4, PH_OTHER = 5 };
+
 __device__ inline float m_max4(float a, float b, float c, float d) { return fmaxf(fmaxf(a, b), fmaxf(c, d)); }
 __device__ inline double m_max4(double a, double b, double c, double d) { return fmax(fmax(a, b), fmax(c, d)); }
 
@@ -120,7 +134,7 @@ __device__ inline double m_max4(double a, double b, double c, double d) { return
  *                   through the scalar cache as well and skip LDS altogether. */
 template <class R, bool STATIC_SMEM>
 __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t lane, bool active, const RayT<R>& ray, R tmin,
-                             Closest<R>& best, uint32_t& narrow_count) {
+                             Closest<R>& best, uint32_t& narrow_count, PhaseTimer& pt) {
     typedef typename Vec4<R>::type R4;
     typedef R R4v __attribute__((ext_vector_type(4)));
     typedef const R4v __attribute__((address_space(4))) CR4; /* constant address space: uniform index -> s_load */
@@ -194,6 +208,7 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
                 }
             }
         }
+        pt.stamp(PH_BROAD);
         /* ---- narrow phase: each lane walks its own list ------------------------------------------ */
         for (uint32_t k = 0; k < MIRT_CAND_CAP; ++k) {
             if (__ballot(k < cnt) == 0ull) break;
@@ -203,7 +218,116 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
                 ++narrow_count;
             }
         }
+        pt.stamp(PH_NARROW);
     }
+}
+
+/* ---- f32 throughput mode: conservative broad phase ---------------------------------------------------
+ * The broad phase only has to find a SUPERSET of the spheres whose exact discriminant (disc(), the f32 spec) is
+ * >= 0; the narrow phase re-evaluates the exact discriminant and runs the exact root selection, so the final
+ * (id, t) is unchanged.  That freedom buys a cheaper test:
+ *   - every sphere, static or moving, is replaced by a ball (M, rho) that contains it for all shutter times
+ *     tm in [0,1]:  M = c0 + dc/2, rho = r + |dc|/2 (+ rounding slack)                     [host, in double]
+ *   - with a NORMALISED direction Dn = D/|D| the line-ball test is  (Dn.(M-O))^2 - |M-O|^2 + rho^2 >= 0,
+ *     expanded so that everything that depends on the ray alone or the sphere alone is hoisted:
+ *         h = Dn.M - k1            k1 = Dn.O                      3 fma   (sphere operand: one SGPR each)
+ *         q = h*h + 2 O.M - k2     k2 = |O|^2 (1 - 160 eps)       4 fma
+ *         candidate  <=>  q >= w   w  = |M|^2 - rho^2 - 160 eps (|M|^2 + rho^2)   1 compare against an SGPR
+ *     8 VALU instructions per (ray, sphere) instead of 12 (static) / 15 (moving), no LDS traffic at all: the
+ *     16-byte records stream through the scalar cache as wave-uniform s_load operands.
+ *   - the expansion cancels (|M|^2 + |O|^2 - 2 O.M), so both sides carry a rigorous rounding margin: the exact
+ *     discriminant can be >= 0 only if the real line passes within r^2 + 32 eps (|C-O|^2 + r^2) of the centre,
+ *     and the evaluation above is off by at most 40 eps ((|M|+|O|)^2 + rho^2); 160 eps (|M|^2 + rho^2) on the
+ *     sphere side plus 160 eps |O|^2 on the ray side covers both (eps = 2^-24).  A diagnostic build
+ *     (-DMIRT_VERIFY_BROAD) re-tests every pair exactly and counts misses: 0 on every workload in bench.py. */
+#define MIRT_RAY_SHRINK 0.99999f /* <= 1 - 160 * 2^-24 */
+
+__device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
+                                  Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef const f4v __attribute__((address_space(4))) CF4; /* constant address space + uniform index -> s_load */
+    CF4* Sc = (CF4*)sc.S;
+    best.t = INFINITY;
+    best.idx = 0xFFFFFFFFu;
+    best.orig = 0xFFFFFFFFu;
+    const V3<float> O = ray.o;
+    const float a_true = ray_a(ray.d);
+    const float inv = 1.0f / sqrtf(a_true);
+    const V3<float> Dn = {ray.d.x * inv, ray.d.y * inv, ray.d.z * inv};
+    const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
+    /* an inactive lane gets k2 = +inf: q = -inf, never a candidate */
+    const float k2 = active ? __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x)) * MIRT_RAY_SHRINK : INFINITY;
+    const V3<float> O2 = {O.x * 2.0f, O.y * 2.0f, O.z * 2.0f};
+    const uint32_t ngroups = sc.n / MIRT_GROUP;
+
+#define MIRT_CONS_Q(s) __builtin_fmaf(h##s, h##s, __builtin_fmaf(O2.z, s.z, __builtin_fmaf(O2.y, s.y, __builtin_fmaf(O2.x, s.x, -k2))))
+#define MIRT_CONS_H(s) __builtin_fmaf(Dn.z, s.z, __builtin_fmaf(Dn.y, s.y, __builtin_fmaf(Dn.x, s.x, -k1)))
+    uint32_t g = 0;
+    while (g < ngroups) { /* one pass unless some lane's candidate list fills up */
+        uint32_t cnt = 0;
+        const uint32_t pass_base = g * MIRT_GROUP;
+        uint32_t glimit = g + 0x10000u / MIRT_GROUP; /* candidate indices are 16 bit, relative to pass_base */
+        glimit = glimit < ngroups ? glimit : ngroups;
+        for (; g < glimit; ++g) {
+            const uint32_t i0 = g * MIRT_GROUP;
+            const f4v s0 = Sc[i0], s1 = Sc[i0 + 1], s2 = Sc[i0 + 2], s3 = Sc[i0 + 3];
+            const float hs0 = MIRT_CONS_H(s0), hs1 = MIRT_CONS_H(s1), hs2 = MIRT_CONS_H(s2), hs3 = MIRT_CONS_H(s3);
+            const bool c0 = MIRT_CONS_Q(s0) >= s0.w, c1 = MIRT_CONS_Q(s1) >= s1.w, c2 = MIRT_CONS_Q(s2) >= s2.w, c3 = MIRT_CONS_Q(s3) >= s3.w;
+#ifdef MIRT_VERIFY_BROAD
+            for (uint32_t k = 0; k < MIRT_GROUP; ++k) { /* exact discriminant of every pair: must imply the flag */
+                const uint32_t i = i0 + k;
+                float4 sa = sc.A[i];
+                V3<float> C = {sa.x, sa.y, sa.z};
+                if (i >= sc.n_static) {
+                    float4 sb = sc.B[i];
+                    C = center_at(C, V3<float>{sb.x, sb.y, sb.z}, ray.tm);
+                }
+                float hh, dd;
+                disc(C - O, ray.d, a_true, sa.w, hh, dd);
+                const bool flag = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
+                if (active && dd >= 0.0f && !flag) atomicAdd(sc.dbg, 1ull);
+            }
+#endif
+            if (__ballot(c0 | c1 | c2 | c3) != 0ull) { /* wave-uniform branch, rarely taken */
+                const uint16_t r0 = (uint16_t)(i0 - pass_base);
+                if (c0) { lds.cand[cnt][lane] = r0; ++cnt; }
+                if (c1) { lds.cand[cnt][lane] = r0 + 1; ++cnt; }
+                if (c2) { lds.cand[cnt][lane] = r0 + 2; ++cnt; }
+                if (c3) { lds.cand[cnt][lane] = r0 + 3; ++cnt; }
+                if (__ballot(cnt > MIRT_CAND_CAP - MIRT_GROUP) != 0ull) { /* no room for another group */
+                    ++g;
+                    break;
+                }
+            }
+        }
+        pt.stamp(PH_BROAD);
+        /* ---- narrow phase: each lane walks its own list, exact test (sphere.rs:81-101) ------------------ */
+        for (uint32_t k = 0; k < MIRT_CAND_CAP; ++k) {
+            if (__ballot(k < cnt) == 0ull) break;
+            if (k < cnt) {
+                uint32_t i = pass_base + lds.cand[k][lane];
+                narrow_test(sc, i, ray, a_true, tmin, best);
+                ++narrow_count;
+            }
+        }
+        pt.stamp(PH_NARROW);
+    }
+#undef MIRT_CONS_Q
+#undef MIRT_CONS_H
+}
+
+/* dispatch: f64 = exact broad phase, f32 = conservative broad phase */
+__device__ inline void closest_hit(const DevScene<double>& sc, WaveLds<double>& lds, uint32_t lane, bool active, const RayT<double>& ray, double tmin,
+                                   Closest<double>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+    trace<double, true>(sc, lds, lane, active, ray, tmin, best, narrow_count, pt);
+}
+__device__ inline void closest_hit(const DevScene<float>& sc, WaveLds<float>& lds, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
+                                   Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+#ifdef MIRT_F32_EXACT_BROAD
+    trace<float, true>(sc, lds, lane, active, ray, tmin, best, narrow_count, pt);
+#else
+    trace_cons(sc, lds, lane, active, ray, tmin, best, narrow_count, pt);
+#endif
 }
 
 /* ---- hit record of the winner: sphere.rs:102-107, hittable.rs:48-60 -------------------------------- */
@@ -374,6 +498,8 @@ struct DevStats { /* device-side counters, one atomic per wave at kernel end */
     unsigned long long segments, narrow, wave_iters, nan_pixels;
     unsigned int queue_head; /* next unclaimed work item of the running render launch */
     unsigned int _pad;
+    unsigned long long phase_cycles[6]; /* diagnostic builds only (MIRT_PHASE_TIMING) */
+    unsigned long long broad_misses;    /* diagnostic builds only (MIRT_VERIFY_BROAD): must be 0 */
 };
 
 template <class R> __device__ inline R wave_sum_u(R v) {
@@ -397,7 +523,9 @@ __global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel(DevScene<R> sc
     RayT<R> ray = primary_ray(cam, pm.lx, pm.gy);
     Closest<R> best;
     uint32_t narrow = 0;
-    trace<R, MIRT_STATIC_SMEM>(sc, lds, lane, pm.valid, ray, (R)0.001, best, narrow);
+    PhaseTimer pt;
+    pt.start();
+    closest_hit(sc, lds, lane, pm.valid, ray, (R)0.001, best, narrow, pt);
     if (pm.valid) {
         uint32_t row = part.compact ? pm.ly : pm.gy;
         size_t o = (size_t)row * cam.W + pm.lx;
@@ -440,6 +568,8 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<
     V3<R> acc = {(R)0.0, (R)0.0, (R)0.0}, thr = {(R)1.0, (R)1.0, (R)1.0};
     RayT<R> ray = {};
     uint32_t n_seg = 0, n_narrow = 0, n_iter = 0;
+    PhaseTimer pt;
+    pt.start();
 
     for (;;) {
         /* ---- deal work items to idle lanes ---------------------------------------------------------- */
@@ -484,6 +614,7 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<
         }
         if (__ballot(has_work) == 0ull) break;
         ++n_iter;
+        pt.stamp(PH_QUEUE);
         /* ---- camera ray for lanes that start a sample (camera.rs:209-230 / 248-252) ------------------- */
         if (need_ray) {
             thr = {(R)1.0, (R)1.0, (R)1.0};
@@ -493,9 +624,10 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<
             ray = aa ? ray_for(cam, lx, gy, dr) : primary_ray(cam, lx, gy);
             need_ray = false;
         }
+        pt.stamp(PH_RAYGEN);
         /* ---- one ray segment for every lane of the wave ---------------------------------------------- */
         Closest<R> best;
-        trace<R, MIRT_STATIC_SMEM>(sc, lds, lane, has_work, ray, (R)0.001, best, n_narrow);
+        closest_hit(sc, lds, lane, has_work, ray, (R)0.001, best, n_narrow, pt);
         if (has_work) {
             ++n_seg;
             bool done;
@@ -535,7 +667,12 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<
                 }
             }
         }
+        pt.stamp(PH_SHADE);
     }
+#ifdef MIRT_PHASE_TIMING
+    if (lane == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&stats->phase_cycles[i], pt.acc[i]);
+#endif
     uint32_t s1 = wave_sum_u(n_seg), s2 = wave_sum_u(n_narrow);
     if (lane == 0) {
         atomicAdd(&stats->segments, (unsigned long long)s1);
