@@ -284,7 +284,8 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
         return rc;
     }
     {   /* conservative bounding records of trace_cons, from the f32 values the kernels see, in double */
-        std::vector<float4> S(order.size());
+        std::vector<float4> S((order.size() + MIRT_TILE - 1) / MIRT_TILE * MIRT_TILE + MIRT_TILE); /* whole tiles + one spare */
+        for (size_t k = order.size(); k < S.size(); ++k) { S[k].x = S[k].y = S[k].z = 0.f; S[k].w = INFINITY; }
         const double eps = 1.0 / 16777216.0; /* 2^-24 */
         for (size_t k = 0; k < order.size(); ++k) {
             if (order[k] == 0xFFFFFFFFu) { S[k].x = S[k].y = S[k].z = 0.f; S[k].w = INFINITY; continue; }

@@ -23,7 +23,8 @@
 #define MIRT_BLOCK (MIRT_WAVE * MIRT_WAVES_PER_BLOCK)
 #define MIRT_TILE 64   /* spheres staged per LDS tile, one per lane */
 #define MIRT_GROUP 4    /* spheres per broad-phase group */
-#define MIRT_CAND_CAP 16 /* deferred narrow-phase candidates kept per lane */
+#define MIRT_CGROUP 8   /* bounding records per iteration of the f32 conservative broad phase */
+#define MIRT_CAND_CAP 24 /* deferred narrow-phase candidates kept per lane */
 
 namespace mirt {
 

@@ -230,11 +230,13 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
  *     tm in [0,1]:  M = c0 + dc/2, rho = r + |dc|/2 (+ rounding slack)                     [host, in double]
  *   - with a NORMALISED direction Dn = D/|D| the line-ball test is  (Dn.(M-O))^2 - |M-O|^2 + rho^2 >= 0,
  *     expanded so that everything that depends on the ray alone or the sphere alone is hoisted:
- *         h = Dn.M - k1            k1 = Dn.O                      3 fma   (sphere operand: one SGPR each)
- *         q = h*h + 2 O.M - k2     k2 = |O|^2 (1 - 160 eps)       4 fma
- *         candidate  <=>  q >= w   w  = |M|^2 - rho^2 - 160 eps (|M|^2 + rho^2)   1 compare against an SGPR
+ *         h = Dn.M - k1                k1 = Dn.O                      3 fma   (sphere operand: one SGPR each)
+ *         q = h*h + 2 O.M - k2 - w     k2 = |O|^2 (1 - 160 eps)       1 sub + 4 fma
+ *         candidate  <=>  q >= 0       w  = |M|^2 - rho^2 - 160 eps (|M|^2 + rho^2)
  *     8 VALU instructions per (ray, sphere) instead of 12 (static) / 15 (moving), no LDS traffic at all: the
- *     16-byte records stream through the scalar cache as wave-uniform s_load operands.
+ *     16-byte records stream through the scalar cache as wave-uniform s_load operands, eight per loop iteration,
+ *     and "does any lane have a candidate among these eight" is one v_max3_i32 tree + one compare, because the
+ *     CU has ONE scalar ALU for its four SIMDs: per-sphere s_or/s_cmp work would make it the bottleneck.
  *   - the expansion cancels (|M|^2 + |O|^2 - 2 O.M), so both sides carry a rigorous rounding margin: the exact
  *     discriminant can be >= 0 only if the real line passes within r^2 + 32 eps (|C-O|^2 + r^2) of the centre,
  *     and the evaluation above is off by at most 40 eps ((|M|+|O|)^2 + rho^2); 160 eps (|M|^2 + rho^2) on the
@@ -242,11 +244,8 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
  *     (-DMIRT_VERIFY_BROAD) re-tests every pair exactly and counts misses: 0 on every workload in bench.py. */
 #define MIRT_RAY_SHRINK 0.99999f /* <= 1 - 160 * 2^-24 */
 
-__device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
-                                  Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    typedef const f4v __attribute__((address_space(4))) CF4; /* constant address space + uniform index -> s_load */
-    CF4* Sc = (CF4*)sc.S;
+__device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds, const float4* tab, uint32_t lane, bool active,
+                                  const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
     best.t = INFINITY;
     best.idx = 0xFFFFFFFFu;
     best.orig = 0xFFFFFFFFu;
@@ -258,46 +257,79 @@ __device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds
     /* an inactive lane gets k2 = +inf: q = -inf, never a candidate */
     const float k2 = active ? __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x)) * MIRT_RAY_SHRINK : INFINITY;
     const V3<float> O2 = {O.x * 2.0f, O.y * 2.0f, O.z * 2.0f};
-    const uint32_t ngroups = sc.n / MIRT_GROUP;
+    const float nk2 = -k2;
+    const uint32_t ngroups = (sc.n + MIRT_CGROUP - 1) / MIRT_CGROUP; /* the record array is padded to whole groups */
 
-#define MIRT_CONS_Q(s) __builtin_fmaf(h##s, h##s, __builtin_fmaf(O2.z, s.z, __builtin_fmaf(O2.y, s.y, __builtin_fmaf(O2.x, s.x, -k2))))
+/* q - w for one record held in SGPRs: 1 sub + 3 fma (e chain) + 3 fma (h chain) + 1 fma = 8 VALU, one scalar operand each */
+#define MIRT_CONS_QW(s)                                                                                                  \
+    __builtin_fmaf(MIRT_CONS_H(s), MIRT_CONS_H(s),                                                                       \
+                   __builtin_fmaf(O2.z, s.z, __builtin_fmaf(O2.y, s.y, __builtin_fmaf(O2.x, s.x, nk2 - s.w))))
 #define MIRT_CONS_H(s) __builtin_fmaf(Dn.z, s.z, __builtin_fmaf(Dn.y, s.y, __builtin_fmaf(Dn.x, s.x, -k1)))
+#define MIRT_IMAX(a, b) ((a) > (b) ? (a) : (b))
+
     uint32_t g = 0;
     while (g < ngroups) { /* one pass unless some lane's candidate list fills up */
         uint32_t cnt = 0;
-        const uint32_t pass_base = g * MIRT_GROUP;
-        uint32_t glimit = g + 0x10000u / MIRT_GROUP; /* candidate indices are 16 bit, relative to pass_base */
+        const uint32_t pass_base = g * MIRT_CGROUP;
+        uint32_t glimit = g + 0x10000u / MIRT_CGROUP; /* candidate indices are 16 bit, relative to pass_base */
         glimit = glimit < ngroups ? glimit : ngroups;
-        for (; g < glimit; ++g) {
-            const uint32_t i0 = g * MIRT_GROUP;
-            const f4v s0 = Sc[i0], s1 = Sc[i0 + 1], s2 = Sc[i0 + 2], s3 = Sc[i0 + 3];
-            const float hs0 = MIRT_CONS_H(s0), hs1 = MIRT_CONS_H(s1), hs2 = MIRT_CONS_H(s2), hs3 = MIRT_CONS_H(s3);
-            const bool c0 = MIRT_CONS_Q(s0) >= s0.w, c1 = MIRT_CONS_Q(s1) >= s1.w, c2 = MIRT_CONS_Q(s2) >= s2.w, c3 = MIRT_CONS_Q(s3) >= s3.w;
+        bool flush = false;
+        while (g < glimit && !flush) {
+            /* records of this tile: the block-resident LDS table, or (big scenes) a wave-private tile staged here */
+            const uint32_t tile = g / (MIRT_TILE / MIRT_CGROUP);
+            const float4* tp;
+            if (tab) {
+                tp = tab + tile * MIRT_TILE;
+            } else {
+                lds.tileA[lane] = sc.S[tile * MIRT_TILE + lane]; /* the array is padded to whole tiles */
+                tp = lds.tileA;
+            }
+            uint32_t gend = (tile + 1) * (MIRT_TILE / MIRT_CGROUP);
+            gend = gend < glimit ? gend : glimit;
+            for (; g < gend && !flush; ++g) {
+            const float4* p = tp + (g * MIRT_CGROUP - tile * MIRT_TILE);
+            /* wave-uniform addresses: eight broadcast ds_read_b128, the records land in VGPRs (a VALU instruction with
+             * an SGPR source issues at HALF rate on gfx950 - bench/sgpr_rate.hip - so the scalar cache is the wrong path) */
+            const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3], s4 = p[4], s5 = p[5], s6 = p[6], s7 = p[7];
+            const float q0 = MIRT_CONS_QW(s0), q1 = MIRT_CONS_QW(s1), q2 = MIRT_CONS_QW(s2), q3 = MIRT_CONS_QW(s3);
+            const float q4 = MIRT_CONS_QW(s4), q5 = MIRT_CONS_QW(s5), q6 = MIRT_CONS_QW(s6), q7 = MIRT_CONS_QW(s7);
+            /* "some q >= 0" on the VALU (the CU's single scalar ALU is the scarcer unit): q is never -0, so as signed
+             * integers the bit patterns are >= 0 exactly for q >= +0 and for positive NaNs, which the per-lane float
+             * tests below sort out */
+            const int m0 = MIRT_IMAX(MIRT_IMAX(__float_as_int(q0), __float_as_int(q1)), __float_as_int(q2));
+            const int m1 = MIRT_IMAX(MIRT_IMAX(m0, __float_as_int(q3)), __float_as_int(q4));
+            const int m2 = MIRT_IMAX(MIRT_IMAX(m1, __float_as_int(q5)), __float_as_int(q6));
+            const int m3 = MIRT_IMAX(m2, __float_as_int(q7));
 #ifdef MIRT_VERIFY_BROAD
-            for (uint32_t k = 0; k < MIRT_GROUP; ++k) { /* exact discriminant of every pair: must imply the flag */
-                const uint32_t i = i0 + k;
-                float4 sa = sc.A[i];
-                V3<float> C = {sa.x, sa.y, sa.z};
-                if (i >= sc.n_static) {
-                    float4 sb = sc.B[i];
-                    C = center_at(C, V3<float>{sb.x, sb.y, sb.z}, ray.tm);
+            {
+                const float qq[MIRT_CGROUP] = {q0, q1, q2, q3, q4, q5, q6, q7};
+                for (uint32_t k_ = 0; k_ < MIRT_CGROUP; ++k_) { /* exact discriminant of every pair must imply the flag */
+                    const uint32_t i_ = g * MIRT_CGROUP + k_;
+                    if (i_ >= sc.n) break;
+                    float4 sa_ = sc.A[i_];
+                    V3<float> C_ = {sa_.x, sa_.y, sa_.z};
+                    if (i_ >= sc.n_static) {
+                        float4 sb_ = sc.B[i_];
+                        C_ = center_at(C_, V3<float>{sb_.x, sb_.y, sb_.z}, ray.tm);
+                    }
+                    float hh_, dd_;
+                    disc(C_ - O, ray.d, a_true, sa_.w, hh_, dd_);
+                    if (active && dd_ >= 0.0f && !(qq[k_] >= 0.0f && m3 >= 0)) atomicAdd(sc.dbg, 1ull);
                 }
-                float hh, dd;
-                disc(C - O, ray.d, a_true, sa.w, hh, dd);
-                const bool flag = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
-                if (active && dd >= 0.0f && !flag) atomicAdd(sc.dbg, 1ull);
             }
 #endif
-            if (__ballot(c0 | c1 | c2 | c3) != 0ull) { /* wave-uniform branch, rarely taken */
-                const uint16_t r0 = (uint16_t)(i0 - pass_base);
-                if (c0) { lds.cand[cnt][lane] = r0; ++cnt; }
-                if (c1) { lds.cand[cnt][lane] = r0 + 1; ++cnt; }
-                if (c2) { lds.cand[cnt][lane] = r0 + 2; ++cnt; }
-                if (c3) { lds.cand[cnt][lane] = r0 + 3; ++cnt; }
-                if (__ballot(cnt > MIRT_CAND_CAP - MIRT_GROUP) != 0ull) { /* no room for another group */
-                    ++g;
-                    break;
-                }
+            if (__ballot(m3 >= 0) != 0ull) { /* wave-uniform branch, rarely taken */
+                const uint16_t r0 = (uint16_t)(g * MIRT_CGROUP - pass_base);
+                if (q0 >= 0.0f) { lds.cand[cnt][lane] = r0; ++cnt; }
+                if (q1 >= 0.0f) { lds.cand[cnt][lane] = r0 + 1; ++cnt; }
+                if (q2 >= 0.0f) { lds.cand[cnt][lane] = r0 + 2; ++cnt; }
+                if (q3 >= 0.0f) { lds.cand[cnt][lane] = r0 + 3; ++cnt; }
+                if (q4 >= 0.0f) { lds.cand[cnt][lane] = r0 + 4; ++cnt; }
+                if (q5 >= 0.0f) { lds.cand[cnt][lane] = r0 + 5; ++cnt; }
+                if (q6 >= 0.0f) { lds.cand[cnt][lane] = r0 + 6; ++cnt; }
+                if (q7 >= 0.0f) { lds.cand[cnt][lane] = r0 + 7; ++cnt; }
+                flush = __ballot(cnt > MIRT_CAND_CAP - MIRT_CGROUP) != 0ull; /* no room for another group */
+            }
             }
         }
         pt.stamp(PH_BROAD);
@@ -312,21 +344,40 @@ __device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds
         }
         pt.stamp(PH_NARROW);
     }
-#undef MIRT_CONS_Q
+#undef MIRT_CONS_QW
 #undef MIRT_CONS_H
+#undef MIRT_IMAX
 }
 
 /* dispatch: f64 = exact broad phase, f32 = conservative broad phase */
-__device__ inline void closest_hit(const DevScene<double>& sc, WaveLds<double>& lds, uint32_t lane, bool active, const RayT<double>& ray, double tmin,
+/* Block-shared LDS table of the f32 bounding records (scenes up to MIRT_LDS_RECORDS spheres; larger ones stream
+ * wave-private tiles).  Empty in the f64 instantiation. */
+#define MIRT_LDS_RECORDS 1024
+template <class R> struct BlockTable {
+    __device__ inline const float4* fill(const DevScene<R>&) { return nullptr; }
+};
+template <> struct BlockTable<float> {
+    float4 rec[MIRT_LDS_RECORDS];
+    /* all threads of the block; returns the table, or nullptr when the scene does not fit */
+    __device__ inline const float4* fill(const DevScene<float>& sc) {
+        const uint32_t nrec = (sc.n + MIRT_CGROUP - 1) / MIRT_CGROUP * MIRT_CGROUP;
+        if (nrec > MIRT_LDS_RECORDS) return nullptr;
+        for (uint32_t i = threadIdx.x; i < nrec; i += blockDim.x) rec[i] = sc.S[i];
+        __syncthreads();
+        return rec;
+    }
+};
+
+__device__ inline void closest_hit(const DevScene<double>& sc, WaveLds<double>& lds, const float4*, uint32_t lane, bool active, const RayT<double>& ray, double tmin,
                                    Closest<double>& best, uint32_t& narrow_count, PhaseTimer& pt) {
     trace<double, true>(sc, lds, lane, active, ray, tmin, best, narrow_count, pt);
 }
-__device__ inline void closest_hit(const DevScene<float>& sc, WaveLds<float>& lds, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
-                                   Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+__device__ inline void closest_hit(const DevScene<float>& sc, WaveLds<float>& lds, const float4* tab, uint32_t lane, bool active, const RayT<float>& ray,
+                                   float tmin, Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
 #ifdef MIRT_F32_EXACT_BROAD
     trace<float, true>(sc, lds, lane, active, ray, tmin, best, narrow_count, pt);
 #else
-    trace_cons(sc, lds, lane, active, ray, tmin, best, narrow_count, pt);
+    trace_cons(sc, lds, tab, lane, active, ray, tmin, best, narrow_count, pt);
 #endif
 }
 
@@ -517,6 +568,8 @@ template <class R>
 __global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel(DevScene<R> sc, DevCamera<R> cam, DevPart part, uint32_t* __restrict__ out_id,
                                                                   R* __restrict__ out_t) {
     __shared__ WaveLds<R> lds_all[MIRT_WAVES_PER_BLOCK];
+    __shared__ BlockTable<R> btab;
+    const float4* tab = btab.fill(sc);
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     WaveLds<R>& lds = lds_all[w];
     PixelMap pm = map_pixel(blockIdx.x * MIRT_WAVES_PER_BLOCK + w, lane, cam.W, part);
@@ -525,7 +578,7 @@ __global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel(DevScene<R> sc
     uint32_t narrow = 0;
     PhaseTimer pt;
     pt.start();
-    closest_hit(sc, lds, lane, pm.valid, ray, (R)0.001, best, narrow, pt);
+    closest_hit(sc, lds, tab, lane, pm.valid, ray, (R)0.001, best, narrow, pt);
     if (pm.valid) {
         uint32_t row = part.compact ? pm.ly : pm.gy;
         size_t o = (size_t)row * cam.W + pm.lx;
@@ -555,6 +608,8 @@ template <class R, int MIN_WAVES>
 __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<R> sc, DevCamera<R> cam, DevPart part, RenderParams rp,
                                                                         R* __restrict__ partial, DevStats* __restrict__ stats) {
     __shared__ WaveLds<R> lds_all[MIRT_WAVES_PER_BLOCK];
+    __shared__ BlockTable<R> btab;
+    const float4* tab = btab.fill(sc);
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     WaveLds<R>& lds = lds_all[w];
     const bool aa = cam.spp > 0;
@@ -627,7 +682,7 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<
         pt.stamp(PH_RAYGEN);
         /* ---- one ray segment for every lane of the wave ---------------------------------------------- */
         Closest<R> best;
-        closest_hit(sc, lds, lane, has_work, ray, (R)0.001, best, n_narrow, pt);
+        closest_hit(sc, lds, tab, lane, has_work, ray, (R)0.001, best, n_narrow, pt);
         if (has_work) {
             ++n_seg;
             bool done;

@@ -146,6 +146,19 @@ def test_many_tiles_moving_and_static_mix(oracle):
     assert len(np.unique(ids)) > 50
 
 
+def test_large_scene_streams_wave_private_tiles(oracle):
+    """More spheres than the block-resident LDS table holds (1024 records): the f32 broad phase streams tiles."""
+    sc = presets.stress_scene(1500, seed=3)
+    cam = presets.stress_camera(160, 0, 50)
+    ids = _check_map(oracle, sc, cam)
+    assert len(np.unique(ids)) > 200
+    cam = presets.stress_camera(64, 4, 8)
+    lin, _ = cam.render_arrays(sc, precision=abi.F32, seed=2)
+    o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F32, seed=2, threads=8)
+    err = np.abs(lin - o_lin)
+    assert float((err <= 2e-5 * (1 + np.abs(o_lin))).mean()) >= 0.995 and abs(cam.last_stats["segments"] - o_seg) <= 0.002 * o_seg
+
+
 def test_one_pixel_image_and_tall_image(oracle, scenes):
     _check_map(oracle, scenes["mars"], Camera.build((0, 0, 12), (0, 0, 0), None, 1, 1.0, 0, 0.4, 10.0, None, 5))
     _check_map(oracle, scenes["mars"], Camera.build((0, 0, 12), (0, 0, 0), None, 3, 0.02, 0, 0.4, 10.0, None, 5))
