@@ -41,6 +41,7 @@ def gather_bands(band, world_size: int):
 
     if world_size == 1:
         return band.unsqueeze(0)
-    out = torch.empty((world_size,) + tuple(band.shape), dtype=band.dtype, device=band.device)
+    # concatenated-along-dim-0 output: the one layout both RCCL and gloo accept
+    out = torch.empty((world_size * band.shape[0],) + tuple(band.shape[1:]), dtype=band.dtype, device=band.device)
     td.all_gather_into_tensor(out, band.contiguous())
-    return out
+    return out.view((world_size,) + tuple(band.shape))
