@@ -521,12 +521,16 @@ template <class R> struct Cam {
           W(c.img_width), H(c.img_height), spp(c.samples_per_pixel), depth(c.max_bounce_depth) {}
 };
 
+/* closest-hit queries of this thread; folded into Scene::segments once per row (a shared atomic in the
+ * recursion serialises the worker threads on one cache line) */
+static thread_local uint64_t tl_segments = 0;
+
 /* camera.rs:268-286, recursion kept (the product is evaluated innermost-first). */
 template <class R>
 static V3<R> color(const Scene<R>& sc, const Ray<R>& ray, uint32_t depth, Draws<R> dr, bool use_bvh) {
     if (depth == 0) return {(R)0.0, (R)0.0, (R)0.0};
     HitRec<R> rec;
-    sc.segments.fetch_add(1, std::memory_order_relaxed);
+    ++tl_segments;
     if (sc.hit(ray, Interval<R>{(R)0.001, std::numeric_limits<R>::infinity()}, rec, use_bvh)) {
         V3<R> att{(R)0.0, (R)0.0, (R)0.0};
         Ray<R> sca{};
@@ -579,6 +583,7 @@ template <class R>
 static int render_rows(const Scene<R>& sc, const Cam<R>& cam, uint64_t seed, bool use_bvh, uint32_t row0, uint32_t row1, R* lin,
                        uint8_t* rgb8) {
     int nan = 0;
+    const uint64_t seg0 = tl_segments;
     for (uint32_t hn = row0; hn < row1; ++hn)
         for (uint32_t wn = 0; wn < cam.W; ++wn) {
             V3<R> px{(R)0.0, (R)0.0, (R)0.0};
@@ -602,6 +607,7 @@ static int render_rows(const Scene<R>& sc, const Cam<R>& cam, uint64_t seed, boo
                 if (!quantize(px.z, rgb8[o + 2])) ++nan;
             }
         }
+    sc.segments.fetch_add(tl_segments - seg0, std::memory_order_relaxed);
     return nan;
 }
 
