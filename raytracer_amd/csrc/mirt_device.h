@@ -23,8 +23,8 @@
 #define MIRT_BLOCK (MIRT_WAVE * MIRT_WAVES_PER_BLOCK)
 #define MIRT_TILE 64   /* spheres staged per LDS tile, one per lane */
 #define MIRT_GROUP 4    /* spheres per broad-phase group */
-#define MIRT_CGROUP 8   /* bounding records per iteration of the f32 conservative broad phase */
-#define MIRT_CAND_CAP 24 /* deferred narrow-phase candidates kept per lane */
+#define MIRT_CGROUP 16  /* bounding records per iteration of the f32 conservative broad phase */
+#define MIRT_CAND_CAP 32 /* deferred narrow-phase candidates kept per lane (16-bit; the f32 path keeps 16 32-bit entries) */
 
 namespace mirt {
 

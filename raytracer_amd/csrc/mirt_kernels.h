@@ -230,19 +230,25 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
  *     tm in [0,1]:  M = c0 + dc/2, rho = r + |dc|/2 (+ rounding slack)                     [host, in double]
  *   - with a NORMALISED direction Dn = D/|D| the line-ball test is  (Dn.(M-O))^2 - |M-O|^2 + rho^2 >= 0,
  *     expanded so that everything that depends on the ray alone or the sphere alone is hoisted:
- *         h = Dn.M - k1                k1 = Dn.O                      3 fma   (sphere operand: one SGPR each)
+ *         h = Dn.M - k1                k1 = Dn.O                      3 fma
  *         q = h*h + 2 O.M - k2 - w     k2 = |O|^2 (1 - 160 eps)       1 sub + 4 fma
  *         candidate  <=>  q >= 0       w  = |M|^2 - rho^2 - 160 eps (|M|^2 + rho^2)
- *     8 VALU instructions per (ray, sphere) instead of 12 (static) / 15 (moving), no LDS traffic at all: the
- *     16-byte records stream through the scalar cache as wave-uniform s_load operands, eight per loop iteration,
- *     and "does any lane have a candidate among these eight" is one v_max3_i32 tree + one compare, because the
- *     CU has ONE scalar ALU for its four SIMDs: per-sphere s_or/s_cmp work would make it the bottleneck.
+ *     8 VALU instructions per (ray, sphere) instead of 12 (static) / 15 (moving), one 16-byte record per sphere.
+ *   - the records come from LDS as wave-uniform broadcast ds_read_b128 into VGPRs, sixteen per loop iteration (a VALU
+ *     instruction with an SGPR source issues at HALF rate on gfx950 - bench/sgpr_rate.hip - and the CU has ONE scalar
+ *     ALU for its four SIMDs, so neither the scalar cache nor per-sphere scalar work is affordable).
+ *   - what a lane remembers: the sign bit of every q is shifted into a per-lane word (v_alignbit_b32, ONE VALU op
+ *     per pair), and once per group of sixteen the word (group number << 16 | sign bits) is written to the lane's
+ *     entry list in LDS UNCONDITIONALLY; the list cursor advances only if some sign bit says "candidate".  No
+ *     branch, no exec-mask juggling per sphere: with incoherent bounce rays some lane has a candidate in almost
+ *     every group, so a "rarely taken" slow path does not exist (the first version had one: 8 branches per group).
  *   - the expansion cancels (|M|^2 + |O|^2 - 2 O.M), so both sides carry a rigorous rounding margin: the exact
  *     discriminant can be >= 0 only if the real line passes within r^2 + 32 eps (|C-O|^2 + r^2) of the centre,
  *     and the evaluation above is off by at most 40 eps ((|M|+|O|)^2 + rho^2); 160 eps (|M|^2 + rho^2) on the
  *     sphere side plus 160 eps |O|^2 on the ray side covers both (eps = 2^-24).  A diagnostic build
  *     (-DMIRT_VERIFY_BROAD) re-tests every pair exactly and counts misses: 0 on every workload in bench.py. */
 #define MIRT_RAY_SHRINK 0.99999f /* <= 1 - 160 * 2^-24 */
+#define MIRT_ENT_CAP (MIRT_CAND_CAP / 2) /* 32-bit entries in the space of the 16-bit candidate list */
 
 __device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds, const float4* tab, uint32_t lane, bool active,
                                   const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
@@ -258,20 +264,23 @@ __device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds
     const float k2 = active ? __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x)) * MIRT_RAY_SHRINK : INFINITY;
     const V3<float> O2 = {O.x * 2.0f, O.y * 2.0f, O.z * 2.0f};
     const float nk2 = -k2;
-    const uint32_t ngroups = (sc.n + MIRT_CGROUP - 1) / MIRT_CGROUP; /* the record array is padded to whole groups */
+    const uint32_t ngroups = (sc.n + MIRT_CGROUP - 1) / MIRT_CGROUP; /* the record array is padded to whole tiles */
+    uint32_t(*ent)[MIRT_WAVE] = reinterpret_cast<uint32_t(*)[MIRT_WAVE]>(lds.cand);
 
-/* q - w for one record held in SGPRs: 1 sub + 3 fma (e chain) + 3 fma (h chain) + 1 fma = 8 VALU, one scalar operand each */
+/* q for one record: 1 sub + 3 fma (e chain) + 3 fma (h chain) + 1 fma = 8 VALU.  q is never -0 (h*h >= +0), so its
+ * sign bit is clear exactly for q >= +0 and for positive NaNs (kept: the exact test sorts them out). */
+#define MIRT_CONS_H(s) __builtin_fmaf(Dn.z, s.z, __builtin_fmaf(Dn.y, s.y, __builtin_fmaf(Dn.x, s.x, -k1)))
 #define MIRT_CONS_QW(s)                                                                                                  \
     __builtin_fmaf(MIRT_CONS_H(s), MIRT_CONS_H(s),                                                                       \
                    __builtin_fmaf(O2.z, s.z, __builtin_fmaf(O2.y, s.y, __builtin_fmaf(O2.x, s.x, nk2 - s.w))))
-#define MIRT_CONS_H(s) __builtin_fmaf(Dn.z, s.z, __builtin_fmaf(Dn.y, s.y, __builtin_fmaf(Dn.x, s.x, -k1)))
-#define MIRT_IMAX(a, b) ((a) > (b) ? (a) : (b))
+/* acc = (acc << 1) | signbit(q) */
+#define MIRT_CONS_PUSH(s) acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(MIRT_CONS_QW(s)), 31)
 
     uint32_t g = 0;
-    while (g < ngroups) { /* one pass unless some lane's candidate list fills up */
+    while (g < ngroups) { /* one pass unless some lane's entry list fills up */
         uint32_t cnt = 0;
-        const uint32_t pass_base = g * MIRT_CGROUP;
-        uint32_t glimit = g + 0x10000u / MIRT_CGROUP; /* candidate indices are 16 bit, relative to pass_base */
+        const uint32_t gbase = g;
+        uint32_t glimit = g + 0x10000u; /* group numbers in the entries are 16 bit, relative to gbase */
         glimit = glimit < ngroups ? glimit : ngroups;
         bool flush = false;
         while (g < glimit && !flush) {
@@ -287,23 +296,20 @@ __device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds
             uint32_t gend = (tile + 1) * (MIRT_TILE / MIRT_CGROUP);
             gend = gend < glimit ? gend : glimit;
             for (; g < gend && !flush; ++g) {
-            const float4* p = tp + (g * MIRT_CGROUP - tile * MIRT_TILE);
-            /* wave-uniform addresses: eight broadcast ds_read_b128, the records land in VGPRs (a VALU instruction with
-             * an SGPR source issues at HALF rate on gfx950 - bench/sgpr_rate.hip - so the scalar cache is the wrong path) */
-            const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3], s4 = p[4], s5 = p[5], s6 = p[6], s7 = p[7];
-            const float q0 = MIRT_CONS_QW(s0), q1 = MIRT_CONS_QW(s1), q2 = MIRT_CONS_QW(s2), q3 = MIRT_CONS_QW(s3);
-            const float q4 = MIRT_CONS_QW(s4), q5 = MIRT_CONS_QW(s5), q6 = MIRT_CONS_QW(s6), q7 = MIRT_CONS_QW(s7);
-            /* "some q >= 0" on the VALU (the CU's single scalar ALU is the scarcer unit): q is never -0, so as signed
-             * integers the bit patterns are >= 0 exactly for q >= +0 and for positive NaNs, which the per-lane float
-             * tests below sort out */
-            const int m0 = MIRT_IMAX(MIRT_IMAX(__float_as_int(q0), __float_as_int(q1)), __float_as_int(q2));
-            const int m1 = MIRT_IMAX(MIRT_IMAX(m0, __float_as_int(q3)), __float_as_int(q4));
-            const int m2 = MIRT_IMAX(MIRT_IMAX(m1, __float_as_int(q5)), __float_as_int(q6));
-            const int m3 = MIRT_IMAX(m2, __float_as_int(q7));
+                const float4* p = tp + (g * MIRT_CGROUP - tile * MIRT_TILE);
+                uint32_t acc = g - gbase;
+                {
+                    const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3], s4 = p[4], s5 = p[5], s6 = p[6], s7 = p[7];
+                    MIRT_CONS_PUSH(s0); MIRT_CONS_PUSH(s1); MIRT_CONS_PUSH(s2); MIRT_CONS_PUSH(s3);
+                    MIRT_CONS_PUSH(s4); MIRT_CONS_PUSH(s5); MIRT_CONS_PUSH(s6); MIRT_CONS_PUSH(s7);
+                }
+                {
+                    const float4 s0 = p[8], s1 = p[9], s2 = p[10], s3 = p[11], s4 = p[12], s5 = p[13], s6 = p[14], s7 = p[15];
+                    MIRT_CONS_PUSH(s0); MIRT_CONS_PUSH(s1); MIRT_CONS_PUSH(s2); MIRT_CONS_PUSH(s3);
+                    MIRT_CONS_PUSH(s4); MIRT_CONS_PUSH(s5); MIRT_CONS_PUSH(s6); MIRT_CONS_PUSH(s7);
+                }
 #ifdef MIRT_VERIFY_BROAD
-            {
-                const float qq[MIRT_CGROUP] = {q0, q1, q2, q3, q4, q5, q6, q7};
-                for (uint32_t k_ = 0; k_ < MIRT_CGROUP; ++k_) { /* exact discriminant of every pair must imply the flag */
+                for (uint32_t k_ = 0; k_ < MIRT_CGROUP; ++k_) { /* exact discriminant >= 0 must imply the candidate bit */
                     const uint32_t i_ = g * MIRT_CGROUP + k_;
                     if (i_ >= sc.n) break;
                     float4 sa_ = sc.A[i_];
@@ -314,39 +320,40 @@ __device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds
                     }
                     float hh_, dd_;
                     disc(C_ - O, ray.d, a_true, sa_.w, hh_, dd_);
-                    if (active && dd_ >= 0.0f && !(qq[k_] >= 0.0f && m3 >= 0)) atomicAdd(sc.dbg, 1ull);
+                    if (active && dd_ >= 0.0f && ((acc >> (MIRT_CGROUP - 1 - k_)) & 1u)) atomicAdd(sc.dbg, 1ull);
                 }
-            }
 #endif
-            if (__ballot(m3 >= 0) != 0ull) { /* wave-uniform branch, rarely taken */
-                const uint16_t r0 = (uint16_t)(g * MIRT_CGROUP - pass_base);
-                if (q0 >= 0.0f) { lds.cand[cnt][lane] = r0; ++cnt; }
-                if (q1 >= 0.0f) { lds.cand[cnt][lane] = r0 + 1; ++cnt; }
-                if (q2 >= 0.0f) { lds.cand[cnt][lane] = r0 + 2; ++cnt; }
-                if (q3 >= 0.0f) { lds.cand[cnt][lane] = r0 + 3; ++cnt; }
-                if (q4 >= 0.0f) { lds.cand[cnt][lane] = r0 + 4; ++cnt; }
-                if (q5 >= 0.0f) { lds.cand[cnt][lane] = r0 + 5; ++cnt; }
-                if (q6 >= 0.0f) { lds.cand[cnt][lane] = r0 + 6; ++cnt; }
-                if (q7 >= 0.0f) { lds.cand[cnt][lane] = r0 + 7; ++cnt; }
-                flush = __ballot(cnt > MIRT_CAND_CAP - MIRT_CGROUP) != 0ull; /* no room for another group */
-            }
+                /* unconditional write, conditional advance (cnt < MIRT_ENT_CAP here: a full list flushes below) */
+                ent[cnt][lane] = acc;
+                cnt += ((acc & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
+                flush = __ballot(cnt >= MIRT_ENT_CAP) != 0ull; /* no room for another entry */
             }
         }
         pt.stamp(PH_BROAD);
-        /* ---- narrow phase: each lane walks its own list, exact test (sphere.rs:81-101) ------------------ */
-        for (uint32_t k = 0; k < MIRT_CAND_CAP; ++k) {
-            if (__ballot(k < cnt) == 0ull) break;
-            if (k < cnt) {
-                uint32_t i = pass_base + lds.cand[k][lane];
-                narrow_test(sc, i, ray, a_true, tmin, best);
-                ++narrow_count;
+        /* ---- narrow phase: each lane walks its own entries, exact test (sphere.rs:81-101) ---------------- */
+        {
+            uint32_t k = 0, m = 0, gi = 0;
+            for (;;) {
+                if (m == 0 && k < cnt) {
+                    const uint32_t e = ent[k][lane];
+                    ++k;
+                    m = ~e & 0xFFFFu; /* never 0: the cursor only advanced past entries with a candidate */
+                    gi = (gbase + (e >> 16)) * MIRT_CGROUP + (MIRT_CGROUP - 1);
+                }
+                if (__ballot(m != 0) == 0ull) break;
+                if (m != 0) {
+                    const uint32_t bit = (uint32_t)__ffs((int)m) - 1u; /* sign of record j sits at bit 15 - j */
+                    m &= m - 1u;
+                    narrow_test(sc, gi - bit, ray, a_true, tmin, best);
+                    ++narrow_count;
+                }
             }
         }
         pt.stamp(PH_NARROW);
     }
 #undef MIRT_CONS_QW
 #undef MIRT_CONS_H
-#undef MIRT_IMAX
+#undef MIRT_CONS_PUSH
 }
 
 /* dispatch: f64 = exact broad phase, f32 = conservative broad phase */

@@ -131,6 +131,26 @@ def test_candidate_list_overflow_flush(oracle):
     assert (ids == 39).all()
 
 
+def test_entry_list_overflow_many_groups(oracle):
+    """The f32 path keeps one list entry per group of 16 records with a candidate (16 entries per lane): 600 spheres
+    strung along the view axis put candidates into 38 groups for the central rays, so the list flushes twice per ray.
+    Looked at from the front, from inside the string and from the far end (far-to-near order of the sorted array)."""
+    sc = Scene()
+    m = Lambertian.new((1, 1, 1), 1.0)
+    for k in range(600):
+        if k % 7 == 3:
+            sc.add(Sphere.new(0.4, (0.0, 0.0, -12.0 - 0.9 * k), (0.0, 0.05, -12.0 - 0.9 * k), m))
+        else:
+            sc.add(Sphere.new_static(0.4, (0.0, 0.0, -12.0 - 0.9 * k), m))
+    sc.build_bvh()
+    ids = _check_map(oracle, sc, _cam(24, vfov=0.2))
+    assert (ids == 0).any()
+    ids = _check_map(oracle, sc, _cam(24, lookfrom=(0, 0, -12.0 - 0.9 * 300.5), lookat=(0, 0, -1000), vfov=0.3))
+    assert (ids == 301).any()
+    ids = _check_map(oracle, sc, _cam(24, lookfrom=(0, 0.01, -700), lookat=(0, 0, 0), vfov=0.2))
+    assert (ids == 599).any()
+
+
 def test_many_tiles_moving_and_static_mix(oracle):
     rng = np.random.default_rng(5)
     sc = Scene()
