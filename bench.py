@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets N ranks rehearse the N>1 path on ONE GPU")
     args = ap.parse_args()
 
     import torch
@@ -98,12 +99,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    local_rank %= torch.cuda.device_count()  # rehearsal on a one-GPU box: all ranks share device 0 (gloo only)
     torch.cuda.set_device(local_rank)
     td = None
     if world > 1:
         import torch.distributed as td
 
-        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            td.init_process_group(args.backend)
 
     lib = abi.load()
     scene, cam, scene_name = build_workload(args.workload, args.width, args.spp, args.depth)

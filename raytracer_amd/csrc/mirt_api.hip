@@ -41,6 +41,7 @@ struct mirt_scene {
     int device = 0;
     uint32_t n = 0, n_static = 0;           /* padded counts (multiples of MIRT_GROUP) seen by the kernels */
     uint32_t true_n = 0, true_static = 0;   /* real sphere counts, for the statistics */
+    uint32_t n_materials = 0;
     SceneBuffers<float> f32;
     SceneBuffers<double> f64;
     uint32_t *orig_id = nullptr, *material = nullptr, *texels = nullptr;
@@ -85,9 +86,14 @@ static int upload_real(mirt_scene* s, const mirt_scene_desc* d, const std::vecto
     std::vector<DevMaterial<R>> mats(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const mirt_material& m = d->materials[i];
-        mats[i].kind = m.kind; mats[i].tex = m.texture; mats[i].has_fuzz = m.has_fuzz; mats[i]._pad = 0;
+        mats[i].kind = m.kind; mats[i].tex = m.texture; mats[i].has_fuzz = m.has_fuzz; mats[i].tex_kind = 0xFFFFFFFFu;
         mats[i].reflectance = (R)m.reflectance; mats[i].fuzz = (R)m.fuzz; mats[i].ior = (R)m.ior;
         mats[i].albedo = {(R)m.albedo[0], (R)m.albedo[1], (R)m.albedo[2]};
+        if (m.kind == MIRT_MAT_LAMBERTIAN) { /* validated above: m.texture < n_textures */
+            const mirt_texture& t = d->textures[m.texture];
+            mats[i].tex_kind = t.kind;
+            if (t.kind == MIRT_TEX_SOLID) mats[i].albedo = {(R)t.color[0], (R)t.color[1], (R)t.color[2]};
+        }
     }
     std::vector<DevTexture<R>> texs(d->n_textures);
     for (uint32_t i = 0; i < d->n_textures; ++i) {
@@ -106,6 +112,7 @@ template <class R> static DevScene<R> dev_scene(const mirt_scene* s, const Scene
     d.A = b.A; d.B = b.B; d.orig_id = s->orig_id; d.material = s->material; d.mats = b.mats; d.texs = b.texs;
     d.imgs = s->imgs; d.texels = s->texels; d.n = s->n; d.n_static = s->n_static;
     d.S = sizeof(R) == 4 ? s->S : nullptr;
+    d.n_materials = s->n_materials;
     d.dbg = s->stats ? &s->stats->broad_misses : nullptr;
     return d;
 }
@@ -134,36 +141,57 @@ static int check_common(const mirt_scene* s, const mirt_camera* cam, const mirt_
     if ((uint64_t)cam->img_width * cam->img_height > 0xFFFFFFFFull) return fail(MIRT_ERR_TOO_LARGE, "W*H must fit 32 bits (RNG pixel counter)");
     return MIRT_OK;
 }
-static uint32_t grid_for(uint32_t W, uint32_t local_rows) {
+static uint32_t grid_for(uint32_t W, uint32_t local_rows, uint32_t waves_per_block) {
     uint32_t tiles = ((W + 7) / 8) * ((local_rows + 7) / 8);
-    return (tiles + MIRT_WAVES_PER_BLOCK - 1) / MIRT_WAVES_PER_BLOCK;
+    return (tiles + waves_per_block - 1) / waves_per_block;
 }
 
 /* ---- launches -------------------------------------------------------------------------------- */
-template <class R>
-static int launch_primary(const mirt_scene* s, const SceneBuffers<R>& b, const mirt_camera* cam, const DevPart& part, uint32_t* d_id, void* d_t,
+static int launch_primary(const mirt_scene* s, const SceneBuffers<double>& b, const mirt_camera* cam, const DevPart& part, uint32_t* d_id, void* d_t,
                           hipStream_t st) {
-    uint32_t grid = grid_for(cam->img_width, part.local_rows);
+    uint32_t grid = grid_for(cam->img_width, part.local_rows, MIRT_WAVES_PER_BLOCK);
     if (grid == 0) return MIRT_OK;
-    hipLaunchKernelGGL((primary_hits_kernel<R>), dim3(grid), dim3(MIRT_BLOCK), 0, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, d_id, (R*)d_t);
+    hipLaunchKernelGGL(primary_hits_kernel_f64, dim3(grid), dim3(MIRT_BLOCK), 0, st, dev_scene<double>(s, b), dev_camera<double>(cam), part, d_id, (double*)d_t);
+    HIP_TRY(hipGetLastError());
+    return MIRT_OK;
+}
+static int launch_primary(const mirt_scene* s, const SceneBuffers<float>& b, const mirt_camera* cam, const DevPart& part, uint32_t* d_id, void* d_t,
+                          hipStream_t st) {
+    uint32_t grid = grid_for(cam->img_width, part.local_rows, MIRT_F32_WAVES);
+    if (grid == 0) return MIRT_OK;
+    hipLaunchKernelGGL(primary_hits_kernel_f32, dim3(grid), dim3(MIRT_F32_BLOCK), 0, st, dev_scene<float>(s, b), dev_camera<float>(cam), part, d_id, (float*)d_t);
     HIP_TRY(hipGetLastError());
     return MIRT_OK;
 }
 /* Samples per work item: the partial-sum workspace is capped at MIRT_PARTIAL_BUDGET bytes, and an item should not
  * be smaller than 4 samples (per-item bookkeeping) unless the pixel has fewer. */
-#define MIRT_PARTIAL_BUDGET (512ull << 20)
+#define MIRT_PARTIAL_BUDGET (2048ull << 20)
 static void choose_chunks(uint64_t n_pixels, uint32_t nsamples, size_t real_bytes, uint32_t* chunk, uint32_t* chunks) {
     uint64_t max_chunks = MIRT_PARTIAL_BUDGET / (std::max<uint64_t>(n_pixels, 1) * 3 * real_bytes);
     if (max_chunks < 1) max_chunks = 1;
     uint32_t q = nsamples >= 8 ? 4u : 1u; /* 64 spp -> 16 items of 4 samples per pixel */
+    if (const char* e = getenv("MIRT_CHUNK")) q = (uint32_t)std::max(1, atoi(e)); /* tuning knob */
     while ((nsamples + q - 1) / q > max_chunks) q *= 2;
     *chunk = q;
     *chunks = (nsamples + q - 1) / q;
 }
 
-template <class R, int MIN_WAVES>
+/* the two render kernels behind one name */
+static const void* render_fn(double) { return (const void*)render_kernel_f64<2>; }
+static const void* render_fn(float) { return (const void*)render_kernel_f32; }
+static void launch_render_kernel(uint32_t grid, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam, const DevPart& part,
+                                 const RenderParams& rp, double* partial, DevStats* stats) {
+    hipLaunchKernelGGL(render_kernel_f64<2>, dim3(grid), dim3(MIRT_BLOCK), 0, st, sc, cam, part, rp, partial, stats);
+}
+static void launch_render_kernel(uint32_t grid, hipStream_t st, const DevScene<float>& sc, const DevCamera<float>& cam, const DevPart& part,
+                                 const RenderParams& rp, float* partial, DevStats* stats) {
+    hipLaunchKernelGGL(render_kernel_f32, dim3(grid), dim3(MIRT_F32_BLOCK), 0, st, sc, cam, part, rp, partial, stats);
+}
+
+template <class R>
 static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mirt_camera* cam, const DevPart& part, uint64_t seed, void* d_lin,
                          uint8_t* d_rgb8, hipStream_t st) {
+    const uint32_t block = sizeof(R) == 4 ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;
     uint64_t n_pixels = (uint64_t)cam->img_width * part.local_rows;
     if (n_pixels == 0) return MIRT_OK;
     RenderParams rp;
@@ -173,6 +201,10 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     rp.n_items = (uint32_t)(n_pixels * rp.chunks);
     rp.k0 = (uint32_t)seed;
     rp.k1 = (uint32_t)(seed >> 32);
+    rp.tail_items = 0;
+    rp.d_chunks = make_fastdiv(rp.chunks);
+    rp.d_W = make_fastdiv(cam->img_width);
+    rp.d_strip = make_fastdiv(part.strip_rows);
     size_t need = (size_t)rp.n_items * 3 * sizeof(R);
     if (need > s->partial_bytes) {
         if (s->partial) (void)hipFree(s->partial);
@@ -187,12 +219,13 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     } else {
         /* persistent grid: as many blocks as can be resident, every wave pulls items until the queue is empty */
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<R, MIN_WAVES>, MIRT_BLOCK, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_fn(R()), (int)block, 0));
         if (per_cu < 1) per_cu = 1;
         uint64_t waves_needed = ((uint64_t)rp.n_items + 63) / 64;
-        uint64_t grid = std::min<uint64_t>((uint64_t)s->n_cus * per_cu, (waves_needed + MIRT_WAVES_PER_BLOCK - 1) / MIRT_WAVES_PER_BLOCK);
-        hipLaunchKernelGGL((render_kernel<R, MIN_WAVES>), dim3((uint32_t)grid), dim3(MIRT_BLOCK), 0, st, dev_scene<R>(s, b), dev_camera<R>(cam), part,
-                           rp, (R*)s->partial, s->stats);
+        uint64_t grid = std::min<uint64_t>((uint64_t)s->n_cus * per_cu, (waves_needed + waves_per_block - 1) / waves_per_block);
+        /* the last two full batches per wave are handed out one item per lane at a time */
+        rp.tail_items = (uint32_t)std::min<uint64_t>(grid * waves_per_block * 2 * MIRT_QUEUE_BATCH, rp.n_items);
+        launch_render_kernel((uint32_t)grid, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, rp, (R*)s->partial, s->stats);
         HIP_TRY(hipGetLastError());
     }
     uint32_t rgrid = (uint32_t)((n_pixels + 255) / 256);
@@ -263,6 +296,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
     while (order.size() % MIRT_GROUP) order.push_back(0xFFFFFFFFu);
     s->n = (uint32_t)order.size();
     s->true_n = d->n_spheres;
+    s->n_materials = d->n_materials;
     std::vector<uint32_t> mat(order.size());
     for (size_t k = 0; k < order.size(); ++k) mat[k] = order[k] == 0xFFFFFFFFu ? 0u : d->spheres[order[k]].material;
 
@@ -337,8 +371,8 @@ int mirt_primary_hits_device(const mirt_scene* s, const mirt_camera* cam, const 
     if ((rc = make_part(cam, o, &part))) return rc;
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
-    return o->precision == MIRT_F64 ? launch_primary<double>(s, s->f64, cam, part, d_id, d_t, st)
-                                    : launch_primary<float>(s, s->f32, cam, part, d_id, d_t, st);
+    return o->precision == MIRT_F64 ? launch_primary(s, s->f64, cam, part, d_id, d_t, st)
+                                    : launch_primary(s, s->f32, cam, part, d_id, d_t, st);
 }
 
 int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, void* d_lin, uint8_t* d_rgb8, void* stream,
@@ -356,8 +390,8 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    rc = o->precision == MIRT_F64 ? launch_render<double, 2>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st)
-                                  : launch_render<float, MIRT_F32_MIN_WAVES>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st);
+    rc = o->precision == MIRT_F64 ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st)
+                                  : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st);
     if (stats) {
         if (!rc) {
             hipError_t e = hipEventRecord(e1, st);
@@ -388,6 +422,10 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
                 fprintf(stderr, "[mirt phase timing] wave-cycles:");
                 for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h.phase_cycles[i] / (double)(tot ? tot : 1));
                 fprintf(stderr, "  (total %.3g cycles, %.0f per wave-iteration)\n", (double)tot, (double)tot / (double)(h.wave_iters ? h.wave_iters : 1));
+                double span = (double)(h.end_max - ~h.inv_start_max) * 1e-5; /* 100 MHz ticks -> ms */
+                double life = (double)h.life_sum / (double)(h.n_waves ? h.n_waves : 1) * 1e-5;
+                fprintf(stderr, "[mirt phase timing] %llu waves, first start -> last end %.3f ms, mean wave lifetime %.3f ms (%.1f%% of the span)\n",
+                        h.n_waves, span, life, 100.0 * life / (span > 0 ? span : 1));
             }
 #endif
         }

@@ -78,7 +78,8 @@ template <class R> struct DevTexture {
     V3<R> even, odd;
 };
 template <class R> struct DevMaterial {
-    uint32_t kind, tex, has_fuzz, _pad;
+    uint32_t kind, tex, has_fuzz;
+    uint32_t tex_kind; /* LAMBERTIAN: kind of its texture; a SolidColor's albedo is copied into `albedo` (one load less per bounce) */
     R reflectance, fuzz, ior;
     V3<R> albedo;
 };
@@ -99,6 +100,7 @@ template <class R> struct DevScene {
     const float4* S;
     unsigned long long* dbg;         /* diagnostic builds: counter of broad-phase misses (must stay 0) */
     uint32_t n, n_static;
+    uint32_t n_materials;
 };
 template <class R> struct DevCamera { /* struct Camera, camera/camera.rs:107-120, rounded once to Real */
     V3<R> lookfrom, du, dv, ul, px00, disk_u, disk_v;
@@ -108,6 +110,25 @@ template <class R> struct DevCamera { /* struct Camera, camera/camera.rs:107-120
 struct DevPart { /* interleaved row strips (mirt_opts) */
     uint32_t strip_rows, part_index, part_count, local_rows, compact;
 };
+
+/* unsigned division by a launch-invariant divisor (Granlund & Montgomery 1994, fig. 4.1): ~5 VALU instead of the ~40 of
+ * a 32-bit hardware-less divide; exact for every 32-bit numerator */
+struct FastDiv {
+    uint32_t m, s1, s2;
+};
+__host__ inline FastDiv make_fastdiv(uint32_t d) {
+    uint32_t l = 0;
+    while (l < 32 && (1ull << l) < d) ++l;
+    FastDiv f;
+    f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+__device__ inline uint32_t fastdiv(uint32_t x, const FastDiv& f) {
+    const uint32_t t = __umulhi(x, f.m);
+    return (t + ((x - t) >> f.s1)) >> f.s2;
+}
 
 __host__ __device__ inline uint32_t part_rows(uint32_t height, uint32_t S, uint32_t idx, uint32_t cnt) {
     if (cnt <= 1) return height;

@@ -67,16 +67,25 @@ template <class R> struct WaveLds {
 template <class R> struct Closest {
     R t;
     uint32_t idx;  /* sorted index, 0xFFFFFFFF = none */
-    uint32_t orig; /* hit id */
 };
 
-/* exact per-candidate test: sphere.rs:91-101 against the interval (tmin, best.t), ties -> lowest id */
-template <class R>
-__device__ inline void narrow_test(const DevScene<R>& sc, uint32_t i, const RayT<R>& ray, R a, R tmin, Closest<R>& best) {
-    typename Vec4<R>::type sa = sc.A[i];
+/* Where the exact sphere records of the narrow phase / hit record come from: HBM (through L2), or the block's LDS
+ * copy (f32 kernels, scenes of up to MIRT_LDS_RECORDS spheres: ~100 cycles instead of ~600+ per dependent load). */
+template <class R> struct GeomGlobal {
+    const DevScene<R>& sc;
+    __device__ inline typename Vec4<R>::type a(uint32_t i) const { return sc.A[i]; }
+    __device__ inline typename Vec4<R>::type b(uint32_t i) const { return sc.B[i]; }
+    __device__ inline uint32_t material(uint32_t i) const { return sc.material[i]; }
+};
+
+/* exact per-candidate test: sphere.rs:91-101 against the interval (tmin, best.t), ties -> lowest hit id.  The hit
+ * id of a sphere is only looked up on an exact tie in t (and once for the winner, by the caller). */
+template <class R, class G>
+__device__ inline void narrow_test(const DevScene<R>& sc, const G& geo, uint32_t i, const RayT<R>& ray, R a, R tmin, Closest<R>& best) {
+    typename Vec4<R>::type sa = geo.a(i);
     V3<R> C = {sa.x, sa.y, sa.z};
     if (i >= sc.n_static) {
-        typename Vec4<R>::type sb = sc.B[i];
+        typename Vec4<R>::type sb = geo.b(i);
         C = center_at(C, V3<R>{sb.x, sb.y, sb.z}, ray.tm);
     }
     V3<R> oc = C - ray.o;
@@ -87,18 +96,21 @@ __device__ inline void narrow_test(const DevScene<R>& sc, uint32_t i, const RayT
      * exactly when h*h is normal, so sqrt(d) <= -h: both roots (h -+ sqrt(d))/a are <= 0 < tmin.  Exact shortcut: it
      * rejects only what the root test below would reject, before paying for the sqrt and the two divisions. */
     if (h < -h_normal_min(h) && c > (R)0.0 && tmin >= (R)0.0) return;
-    uint32_t orig = sc.orig_id[i];
     R sq = m_sqrt(d);
+    /* strict interval (utils/interval.rs:37-39); an exact tie with the current best goes to the lower hit id
+     * (never taken while there is no best: t < +inf is required, as in the reference) */
+    auto inside = [&](R t) {
+        return (tmin < t) && (t < best.t || (t == best.t && best.idx != 0xFFFFFFFFu && sc.orig_id[i] < sc.orig_id[best.idx]));
+    };
     R t = (h - sq) / a;
-    bool ok = (tmin < t) && (t < best.t || (t == best.t && orig < best.orig));
+    bool ok = inside(t);
     if (!ok) {
         t = (h + sq) / a;
-        ok = (tmin < t) && (t < best.t || (t == best.t && orig < best.orig));
+        ok = inside(t);
     }
     if (ok) {
         best.t = t;
         best.idx = i;
-        best.orig = orig;
     }
 }
 
@@ -142,7 +154,6 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
     CR4* Bc = (CR4*)sc.B;
     best.t = (R)INFINITY;
     best.idx = 0xFFFFFFFFu;
-    best.orig = 0xFFFFFFFFu;
     /* an inactive lane gets a = NaN: every d is NaN and `d >= 0` is false for free */
     const R a_true = ray_a(ray.d);
     const R a = active ? a_true : (R)NAN;
@@ -214,7 +225,7 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
             if (__ballot(k < cnt) == 0ull) break;
             if (k < cnt) {
                 uint32_t i = pass_base + lds.cand[k][lane];
-                narrow_test(sc, i, ray, a_true, tmin, best);
+                narrow_test(sc, GeomGlobal<R>{sc}, i, ray, a_true, tmin, best);
                 ++narrow_count;
             }
         }
@@ -248,13 +259,52 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
  *     sphere side plus 160 eps |O|^2 on the ray side covers both (eps = 2^-24).  A diagnostic build
  *     (-DMIRT_VERIFY_BROAD) re-tests every pair exactly and counts misses: 0 on every workload in bench.py. */
 #define MIRT_RAY_SHRINK 0.99999f /* <= 1 - 160 * 2^-24 */
-#define MIRT_ENT_CAP (MIRT_CAND_CAP / 2) /* 32-bit entries in the space of the 16-bit candidate list */
 
-__device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds, const float4* tab, uint32_t lane, bool active,
-                                  const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+/* LDS of an f32 block: ONE block of 16 waves per CU (4 waves per SIMD), so that one copy of the scene serves them all.
+ *   resident scenes (<= MIRT_LDS_RECORDS spheres): bounding records S for the broad phase, exact records A, B and
+ *     material ids for the narrow phase and the hit record; nothing about a sphere is read from HBM in the loop
+ *   larger scenes: wave w stages 64-record tiles of S in S[64 w .. 64 w + 63]; A, B, material come from HBM/L2
+ *   ent: per-wave, per-lane entry lists (group number << 16 | inverted sign bits) */
+#define MIRT_F32_WAVES 16
+#define MIRT_F32_BLOCK (MIRT_F32_WAVES * MIRT_WAVE)
+#define MIRT_LDS_RECORDS 1024
+#define MIRT_ENT_CAP 16
+struct F32Lds {
+    float4 S[MIRT_LDS_RECORDS];
+    float4 A[MIRT_LDS_RECORDS];
+    float4 B[MIRT_LDS_RECORDS];
+    uint16_t mat[MIRT_LDS_RECORDS];
+    uint32_t ent[MIRT_F32_WAVES][MIRT_ENT_CAP][MIRT_WAVE];
+    /* all threads of the block; true when the scene is resident */
+    __device__ inline bool fill(const DevScene<float>& sc) {
+        const uint32_t nrec = (sc.n + MIRT_CGROUP - 1) / MIRT_CGROUP * MIRT_CGROUP;
+        const bool res = nrec <= MIRT_LDS_RECORDS && sc.n_materials <= 0x10000u;
+        if (res) {
+            for (uint32_t i = threadIdx.x; i < nrec; i += blockDim.x) {
+                S[i] = sc.S[i]; /* padded to whole tiles on the host */
+                if (i < sc.n) {
+                    A[i] = sc.A[i];
+                    B[i] = sc.B[i];
+                    mat[i] = (uint16_t)sc.material[i];
+                }
+            }
+        }
+        __syncthreads();
+        return res;
+    }
+};
+struct GeomLds {
+    const F32Lds& L;
+    __device__ inline float4 a(uint32_t i) const { return L.A[i]; }
+    __device__ inline float4 b(uint32_t i) const { return L.B[i]; }
+    __device__ inline uint32_t material(uint32_t i) const { return L.mat[i]; }
+};
+
+template <bool RES>
+__device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t w, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
+                                  Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
     best.t = INFINITY;
     best.idx = 0xFFFFFFFFu;
-    best.orig = 0xFFFFFFFFu;
     const V3<float> O = ray.o;
     const float a_true = ray_a(ray.d);
     const float inv = 1.0f / sqrtf(a_true);
@@ -265,7 +315,7 @@ __device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds
     const V3<float> O2 = {O.x * 2.0f, O.y * 2.0f, O.z * 2.0f};
     const float nk2 = -k2;
     const uint32_t ngroups = (sc.n + MIRT_CGROUP - 1) / MIRT_CGROUP; /* the record array is padded to whole tiles */
-    uint32_t(*ent)[MIRT_WAVE] = reinterpret_cast<uint32_t(*)[MIRT_WAVE]>(lds.cand);
+    uint32_t(*ent)[MIRT_WAVE] = L.ent[w];
 
 /* q for one record: 1 sub + 3 fma (e chain) + 3 fma (h chain) + 1 fma = 8 VALU.  q is never -0 (h*h >= +0), so its
  * sign bit is clear exactly for q >= +0 and for positive NaNs (kept: the exact test sorts them out). */
@@ -287,11 +337,11 @@ __device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds
             /* records of this tile: the block-resident LDS table, or (big scenes) a wave-private tile staged here */
             const uint32_t tile = g / (MIRT_TILE / MIRT_CGROUP);
             const float4* tp;
-            if (tab) {
-                tp = tab + tile * MIRT_TILE;
+            if (RES) {
+                tp = L.S + tile * MIRT_TILE;
             } else {
-                lds.tileA[lane] = sc.S[tile * MIRT_TILE + lane]; /* the array is padded to whole tiles */
-                tp = lds.tileA;
+                L.S[w * MIRT_TILE + lane] = sc.S[tile * MIRT_TILE + lane]; /* the array is padded to whole tiles */
+                tp = L.S + w * MIRT_TILE;
             }
             uint32_t gend = (tile + 1) * (MIRT_TILE / MIRT_CGROUP);
             gend = gend < glimit ? gend : glimit;
@@ -344,7 +394,8 @@ __device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds
                 if (m != 0) {
                     const uint32_t bit = (uint32_t)__ffs((int)m) - 1u; /* sign of record j sits at bit 15 - j */
                     m &= m - 1u;
-                    narrow_test(sc, gi - bit, ray, a_true, tmin, best);
+                    if (RES) narrow_test(sc, GeomLds{L}, gi - bit, ray, a_true, tmin, best);
+                    else narrow_test(sc, GeomGlobal<float>{sc}, gi - bit, ray, a_true, tmin, best);
                     ++narrow_count;
                 }
             }
@@ -356,46 +407,14 @@ __device__ inline void trace_cons(const DevScene<float>& sc, WaveLds<float>& lds
 #undef MIRT_CONS_PUSH
 }
 
-/* dispatch: f64 = exact broad phase, f32 = conservative broad phase */
-/* Block-shared LDS table of the f32 bounding records (scenes up to MIRT_LDS_RECORDS spheres; larger ones stream
- * wave-private tiles).  Empty in the f64 instantiation. */
-#define MIRT_LDS_RECORDS 1024
-template <class R> struct BlockTable {
-    __device__ inline const float4* fill(const DevScene<R>&) { return nullptr; }
-};
-template <> struct BlockTable<float> {
-    float4 rec[MIRT_LDS_RECORDS];
-    /* all threads of the block; returns the table, or nullptr when the scene does not fit */
-    __device__ inline const float4* fill(const DevScene<float>& sc) {
-        const uint32_t nrec = (sc.n + MIRT_CGROUP - 1) / MIRT_CGROUP * MIRT_CGROUP;
-        if (nrec > MIRT_LDS_RECORDS) return nullptr;
-        for (uint32_t i = threadIdx.x; i < nrec; i += blockDim.x) rec[i] = sc.S[i];
-        __syncthreads();
-        return rec;
-    }
-};
-
-__device__ inline void closest_hit(const DevScene<double>& sc, WaveLds<double>& lds, const float4*, uint32_t lane, bool active, const RayT<double>& ray, double tmin,
-                                   Closest<double>& best, uint32_t& narrow_count, PhaseTimer& pt) {
-    trace<double, true>(sc, lds, lane, active, ray, tmin, best, narrow_count, pt);
-}
-__device__ inline void closest_hit(const DevScene<float>& sc, WaveLds<float>& lds, const float4* tab, uint32_t lane, bool active, const RayT<float>& ray,
-                                   float tmin, Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
-#ifdef MIRT_F32_EXACT_BROAD
-    trace<float, true>(sc, lds, lane, active, ray, tmin, best, narrow_count, pt);
-#else
-    trace_cons(sc, lds, tab, lane, active, ray, tmin, best, narrow_count, pt);
-#endif
-}
-
 /* ---- hit record of the winner: sphere.rs:102-107, hittable.rs:48-60 -------------------------------- */
 template <class R> struct Hit {
     V3<R> p, n, on; /* on = outward normal (input of Sphere::uv) */
     bool front;
 };
-template <class R> __device__ inline Hit<R> make_hit(const DevScene<R>& sc, const Closest<R>& c, const RayT<R>& ray) {
-    typename Vec4<R>::type sa = sc.A[c.idx];
-    typename Vec4<R>::type sb = sc.B[c.idx];
+template <class R, class G> __device__ inline Hit<R> make_hit(const DevScene<R>& sc, const G& geo, const Closest<R>& c, const RayT<R>& ray) {
+    typename Vec4<R>::type sa = geo.a(c.idx);
+    typename Vec4<R>::type sb = geo.b(c.idx);
     V3<R> C = {sa.x, sa.y, sa.z};
     if (c.idx >= sc.n_static) C = center_at(C, V3<R>{sb.x, sb.y, sb.z}, ray.tm);
     Hit<R> h;
@@ -405,6 +424,32 @@ template <class R> __device__ inline Hit<R> make_hit(const DevScene<R>& sc, cons
     h.n = h.front ? h.on : -h.on;
     return h;
 }
+
+/* ---- closest-hit front ends used by the kernels: f64 = exact broad phase, f32 = conservative broad phase ---- */
+struct TracerF64 {
+    typedef double Real;
+    const DevScene<double>& sc;
+    WaveLds<double>& lds;
+    __device__ inline void closest(uint32_t lane, bool active, const RayT<double>& ray, double tmin, Closest<double>& best, uint32_t& nc, PhaseTimer& pt) {
+        trace<double, true>(sc, lds, lane, active, ray, tmin, best, nc, pt);
+    }
+    __device__ inline Hit<double> hit(const Closest<double>& c, const RayT<double>& ray) const { return make_hit(sc, GeomGlobal<double>{sc}, c, ray); }
+    __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }
+};
+template <bool RES> struct TracerF32 {
+    typedef float Real;
+    const DevScene<float>& sc;
+    F32Lds& L;
+    uint32_t w;
+    __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
+        trace_cons<RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
+    }
+    __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const {
+        if (RES) return make_hit(sc, GeomLds{L}, c, ray);
+        return make_hit(sc, GeomGlobal<float>{sc}, c, ray);
+    }
+    __device__ inline uint32_t material(uint32_t idx) const { return RES ? (uint32_t)L.mat[idx] : sc.material[idx]; }
+};
 
 /* ---- textures: scene/texture.rs ----------------------------------------------------------------- */
 template <class R> __device__ inline int32_t floor_to_i32(R f) { /* Rust `as i32`: saturating, NaN -> 0 */
@@ -463,44 +508,41 @@ template <class R> __device__ inline V3<R> refract(V3<R> uv, V3<R> n, R e) { /* 
     return perp + par;
 }
 
-/* One scatter event.  Returns false when the path is absorbed (black for the whole path, camera.rs:279). */
+/* One scatter event.  Returns false when the path is absorbed (black for the whole path, camera.rs:279).
+ * The bounce's Philox block is evaluated ONCE, before the material switch: a wave usually holds lanes of all three
+ * materials, and divergent branches that each called the generator would run it up to three times. */
 template <class R>
 __device__ inline bool scatter(const DevScene<R>& sc, uint32_t mat, const RayT<R>& rin, const Hit<R>& hit, const Draws<R>& dr, V3<R>& att,
                                RayT<R>& out) {
     const DevMaterial<R>& m = sc.mats[mat];
-    if (m.kind == MIRT_MAT_LAMBERTIAN) { /* material.rs:59-84 */
-        R ua, ub, uc, ud; /* dims: 0 = absorb test, 1..3 = vector */
-        dr.dims0123(ua, ub, uc, ud);
+    R ua, ub, uc, ud; /* dims 0..3 of this bounce */
+    dr.dims0123(ua, ub, uc, ud);
+    if (m.kind == MIRT_MAT_LAMBERTIAN) { /* material.rs:59-84; dims: 0 = absorb test, 1..3 = vector */
         if (!(ua < m.reflectance)) return false;
         V3<R> dir = hit.n + unit(V3<R>{ub, uc, ud}); /* positive-octant quirk of point3.rs:88-93 */
         const R e = (R)1e-8;
         if (m_fabs(dir.x) < e && m_fabs(dir.y) < e && m_fabs(dir.z) < e) dir = hit.n;
         out = {hit.p, dir, rin.tm};
-        att = texture_color(sc, m.tex, hit) / m.reflectance;
+        att = (m.tex_kind == MIRT_TEX_SOLID ? m.albedo : texture_color(sc, m.tex, hit)) / m.reflectance;
         return true;
     }
-    if (m.kind == MIRT_MAT_METAL) { /* material.rs:97-114 */
+    if (m.kind == MIRT_MAT_METAL) { /* material.rs:97-114; dims 0..2 = vector */
         V3<R> refl = reflect(rin.d, hit.n);
-        if (m.has_fuzz) {
-            R ua, ub, uc, ud; /* dims 0..2 = vector */
-            dr.dims0123(ua, ub, uc, ud);
-            refl = unit(refl) + unit(V3<R>{ua, ub, uc}) * m.fuzz;
-        }
+        if (m.has_fuzz) refl = unit(refl) + unit(V3<R>{ua, ub, uc}) * m.fuzz;
         out = {hit.p, refl, rin.tm};
         att = m.albedo;
         return !m.has_fuzz || dot(refl, hit.n) > (R)0.0;
     }
-    /* DIELECTRIC material.rs:126-154 */
+    /* DIELECTRIC material.rs:126-154; dim 0 (the reference short-circuits the draw away under total internal
+     * reflection; with a counter RNG an unused draw changes nothing) */
     att = {(R)1.0, (R)1.0, (R)1.0};
     R ri = hit.front ? (R)1.0 / m.ior : m.ior;
-    V3<R> ud = unit(rin.d);
-    R cos_theta = m_fmin(dot(-ud, hit.n), (R)1.0);
+    V3<R> udir = unit(rin.d);
+    R cos_theta = m_fmin(dot(-udir, hit.n), (R)1.0);
     R sin_theta = m_sqrt((R)1.0 - cos_theta * cos_theta);
     bool refl = ri * sin_theta > (R)1.0;
-    if (!refl) {
-        refl = schlick(cos_theta, ri) > dr.dim0();
-    }
-    V3<R> dir = refl ? reflect(ud, hit.n) : refract(ud, hit.n, ri);
+    if (!refl) refl = schlick(cos_theta, ri) > ua;
+    V3<R> dir = refl ? reflect(udir, hit.n) : refract(udir, hit.n, ri);
     out = {hit.p, dir, rin.tm};
     return true;
 }
@@ -558,6 +600,11 @@ struct DevStats { /* device-side counters, one atomic per wave at kernel end */
     unsigned int _pad;
     unsigned long long phase_cycles[6]; /* diagnostic builds only (MIRT_PHASE_TIMING) */
     unsigned long long broad_misses;    /* diagnostic builds only (MIRT_VERIFY_BROAD): must be 0 */
+    /* diagnostic builds only (MIRT_PHASE_TIMING), in s_memrealtime ticks (100 MHz): */
+    unsigned long long inv_start_max;   /* ~(earliest wave start) */
+    unsigned long long end_max;         /* latest wave end */
+    unsigned long long life_sum;        /* sum over waves of (end - start) */
+    unsigned long long n_waves;
 };
 
 template <class R> __device__ inline R wave_sum_u(R v) {
@@ -571,26 +618,43 @@ template <class R> __device__ inline R wave_sum_u(R v) {
 #endif
 
 /* ---- K1 ------------------------------------------------------------------------------------------ */
-template <class R>
-__global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel(DevScene<R> sc, DevCamera<R> cam, DevPart part, uint32_t* __restrict__ out_id,
-                                                                  R* __restrict__ out_t) {
-    __shared__ WaveLds<R> lds_all[MIRT_WAVES_PER_BLOCK];
-    __shared__ BlockTable<R> btab;
-    const float4* tab = btab.fill(sc);
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    WaveLds<R>& lds = lds_all[w];
-    PixelMap pm = map_pixel(blockIdx.x * MIRT_WAVES_PER_BLOCK + w, lane, cam.W, part);
+template <class T>
+__device__ inline void primary_hits_body(T& tr, const DevScene<typename T::Real>& sc, const DevCamera<typename T::Real>& cam, const DevPart& part,
+                                         uint32_t wave_global, uint32_t lane, uint32_t* __restrict__ out_id, typename T::Real* __restrict__ out_t) {
+    typedef typename T::Real R;
+    PixelMap pm = map_pixel(wave_global, lane, cam.W, part);
     RayT<R> ray = primary_ray(cam, pm.lx, pm.gy);
     Closest<R> best;
     uint32_t narrow = 0;
     PhaseTimer pt;
     pt.start();
-    closest_hit(sc, lds, tab, lane, pm.valid, ray, (R)0.001, best, narrow, pt);
+    tr.closest(lane, pm.valid, ray, (R)0.001, best, narrow, pt);
     if (pm.valid) {
         uint32_t row = part.compact ? pm.ly : pm.gy;
         size_t o = (size_t)row * cam.W + pm.lx;
-        out_id[o] = best.orig; /* 0xFFFFFFFF on a miss */
+        out_id[o] = best.idx != 0xFFFFFFFFu ? sc.orig_id[best.idx] : 0xFFFFFFFFu;
         if (out_t) out_t[o] = best.t;
+    }
+}
+__global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel_f64(DevScene<double> sc, DevCamera<double> cam, DevPart part, uint32_t* __restrict__ out_id,
+                                                                      double* __restrict__ out_t) {
+    __shared__ WaveLds<double> lds_all[MIRT_WAVES_PER_BLOCK];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    TracerF64 tr{sc, lds_all[w]};
+    primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_WAVES_PER_BLOCK + w, lane, out_id, out_t);
+}
+__global__ __launch_bounds__(MIRT_F32_BLOCK) void primary_hits_kernel_f32(DevScene<float> sc, DevCamera<float> cam, DevPart part, uint32_t* __restrict__ out_id,
+                                                                          float* __restrict__ out_t) {
+    __shared__ F32Lds L;
+    const bool res = L.fill(sc);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t wave_global = blockIdx.x * MIRT_F32_WAVES + w;
+    if (res) {
+        TracerF32<true> tr{sc, L, w};
+        primary_hits_body(tr, sc, cam, part, wave_global, lane, out_id, out_t);
+    } else {
+        TracerF32<false> tr{sc, L, w};
+        primary_hits_body(tr, sc, cam, part, wave_global, lane, out_id, out_t);
     }
 }
 
@@ -609,16 +673,14 @@ struct RenderParams {
     uint32_t chunk;      /* samples per chunk */
     uint32_t nsamples;   /* samples per pixel (1 when anti-aliasing is off) */
     uint32_t k0, k1;     /* RNG key */
+    uint32_t tail_items; /* queue tail served in batches of one item per lane (guided self-scheduling) */
+    FastDiv d_chunks, d_W, d_strip; /* divisions by chunks, image width and strip height when an item is decoded */
 };
 
-template <class R, int MIN_WAVES>
-__global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<R> sc, DevCamera<R> cam, DevPart part, RenderParams rp,
-                                                                        R* __restrict__ partial, DevStats* __restrict__ stats) {
-    __shared__ WaveLds<R> lds_all[MIRT_WAVES_PER_BLOCK];
-    __shared__ BlockTable<R> btab;
-    const float4* tab = btab.fill(sc);
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    WaveLds<R>& lds = lds_all[w];
+template <class T>
+__device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, const DevCamera<typename T::Real>& cam, const DevPart& part,
+                                   const RenderParams& rp, typename T::Real* __restrict__ partial, DevStats* __restrict__ stats, uint32_t lane) {
+    typedef typename T::Real R;
     const bool aa = cam.spp > 0;
 
     /* wave-uniform: the reserved range of the queue */
@@ -632,6 +694,9 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<
     uint32_t n_seg = 0, n_narrow = 0, n_iter = 0;
     PhaseTimer pt;
     pt.start();
+#ifdef MIRT_PHASE_TIMING
+    const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     for (;;) {
         /* ---- deal work items to idle lanes ---------------------------------------------------------- */
@@ -645,15 +710,18 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<
             if (!has_work && rank < take) got = q_next + rank;
             q_next += take;
             if (take < n_idle && !exhausted) { /* reserve the next batch: one atomic per wave per batch */
+                /* guided: near the end of the queue (judged by the last head this wave saw) reserve one item per lane
+                 * only, so that no wave sits on a backlog while others have run dry */
+                const uint32_t batch = q_end + rp.tail_items >= rp.n_items ? MIRT_WAVE : MIRT_QUEUE_BATCH;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&stats->queue_head, MIRT_QUEUE_BATCH);
+                if (lane == 0) base = atomicAdd(&stats->queue_head, batch);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= rp.n_items) {
                     exhausted = true;
                     q_next = q_end = 0;
                 } else {
                     q_next = base;
-                    q_end = base + MIRT_QUEUE_BATCH < rp.n_items ? base + MIRT_QUEUE_BATCH : rp.n_items;
+                    q_end = base + batch < rp.n_items ? base + batch : rp.n_items;
                     uint32_t take2 = q_end - q_next;
                     take2 = take2 < n_idle - take ? take2 : n_idle - take;
                     if (!has_work && rank >= take && rank < take + take2) got = q_next + (rank - take);
@@ -661,11 +729,19 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<
                 }
             }
             if (got != 0xFFFFFFFFu) {
-                item = got;
-                const uint32_t pl = got / rp.chunks, ch = got - pl * rp.chunks; /* band pixel, row-major; chunk */
-                const uint32_t ly = pl / cam.W;
+                /* the queue runs through the band from its LAST pixel to its first: the sky gradient is the only light
+                 * and cameras look roughly level, so the cheap one-segment paths (sky, top rows) end up in the tail
+                 * of the launch and the long bounce chains at its start */
+                const uint32_t rev = rp.n_items - 1u - got;
+                item = rev;
+                const uint32_t pl = fastdiv(rev, rp.d_chunks), ch = rev - pl * rp.chunks; /* band pixel, row-major; chunk */
+                const uint32_t ly = fastdiv(pl, rp.d_W);
                 lx = pl - ly * cam.W;
-                gy = part_global_row(part, ly);
+                gy = ly; /* part_global_row(part, ly) */
+                if (part.part_count > 1) {
+                    const uint32_t ls = fastdiv(ly, rp.d_strip);
+                    gy = (ls * part.part_count + part.part_index) * part.strip_rows + (ly - ls * part.strip_rows);
+                }
                 pixel = gy * cam.W + lx; /* RNG key: the global pixel, independent of the partition */
                 sample = ch * rp.chunk;
                 s_end = sample + rp.chunk < rp.nsamples ? sample + rp.chunk : rp.nsamples;
@@ -689,18 +765,18 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<
         pt.stamp(PH_RAYGEN);
         /* ---- one ray segment for every lane of the wave ---------------------------------------------- */
         Closest<R> best;
-        closest_hit(sc, lds, tab, lane, has_work, ray, (R)0.001, best, n_narrow, pt);
+        tr.closest(lane, has_work, ray, (R)0.001, best, n_narrow, pt);
         if (has_work) {
             ++n_seg;
             bool done;
             V3<R> radiance = {(R)0.0, (R)0.0, (R)0.0};
             if (best.idx != 0xFFFFFFFFu) {
-                Hit<R> hit = make_hit(sc, best, ray);
+                Hit<R> hit = tr.hit(best, ray);
                 ++bounce;
                 Draws<R> dr{pixel, sample, bounce, rp.k0, rp.k1};
                 V3<R> att;
                 RayT<R> nxt;
-                if (scatter(sc, sc.material[best.idx], ray, hit, dr, att, nxt)) {
+                if (scatter(sc, tr.material(best.idx), ray, hit, dr, att, nxt)) {
                     thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
                     ray = nxt;
                     --depth_left;
@@ -732,14 +808,43 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel(DevScene<
         pt.stamp(PH_SHADE);
     }
 #ifdef MIRT_PHASE_TIMING
-    if (lane == 0)
+    if (lane == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&stats->phase_cycles[i], pt.acc[i]);
+        const unsigned long long wave_t1 = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&stats->inv_start_max, ~wave_t0);
+        atomicMax(&stats->end_max, wave_t1);
+        atomicAdd(&stats->life_sum, wave_t1 - wave_t0);
+        atomicAdd(&stats->n_waves, 1ull);
+    }
 #endif
     uint32_t s1 = wave_sum_u(n_seg), s2 = wave_sum_u(n_narrow);
     if (lane == 0) {
         atomicAdd(&stats->segments, (unsigned long long)s1);
         atomicAdd(&stats->narrow, (unsigned long long)s2);
         atomicAdd(&stats->wave_iters, (unsigned long long)n_iter);
+    }
+}
+
+template <int MIN_WAVES>
+__global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel_f64(DevScene<double> sc, DevCamera<double> cam, DevPart part, RenderParams rp,
+                                                                            double* __restrict__ partial, DevStats* __restrict__ stats) {
+    __shared__ WaveLds<double> lds_all[MIRT_WAVES_PER_BLOCK];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    TracerF64 tr{sc, lds_all[w]};
+    render_body(tr, sc, cam, part, rp, partial, stats, lane);
+}
+/* one block of 16 waves per CU: 4 waves per SIMD, <= 128 VGPRs */
+__global__ __launch_bounds__(MIRT_F32_BLOCK) void render_kernel_f32(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
+                                                                    float* __restrict__ partial, DevStats* __restrict__ stats) {
+    __shared__ F32Lds L;
+    const bool res = L.fill(sc);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (res) {
+        TracerF32<true> tr{sc, L, w};
+        render_body(tr, sc, cam, part, rp, partial, stats, lane);
+    } else {
+        TracerF32<false> tr{sc, L, w};
+        render_body(tr, sc, cam, part, rp, partial, stats, lane);
     }
 }
 
