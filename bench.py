@@ -189,7 +189,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
                 "traffic": None,
-                "kernel": "render_kernel<float>" if args.precision == 32 else "render_kernel<double>",
+                "kernel": "render_kernel_f32" if args.precision == 32 else "render_kernel_f64<2>",
                 "kernel_ms_avg": round(kern_ms / max(1, len(stats)), 3),
                 "flops_per_segment": round(flops / max(seg, 1), 1),
                 "note": "algorithmic flops = 18/static sphere test + 27/moving sphere test + 5/segment (SURVEY.md 8d); rank 0's launches",

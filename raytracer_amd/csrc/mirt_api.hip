@@ -163,13 +163,15 @@ static int launch_primary(const mirt_scene* s, const SceneBuffers<float>& b, con
     HIP_TRY(hipGetLastError());
     return MIRT_OK;
 }
-/* Samples per work item: the partial-sum workspace is capped at MIRT_PARTIAL_BUDGET bytes, and an item should not
- * be smaller than 4 samples (per-item bookkeeping) unless the pixel has fewer. */
-#define MIRT_PARTIAL_BUDGET (2048ull << 20)
+/* Samples per work item.  A lane runs the samples of its item back to back, so the launch cannot end before its
+ * longest item has: samples of one pixel are correlated (all 64 samples of a pixel on a glass ball bounce to the depth
+ * limit), and with 4 samples per item the tail of a 1/8-frame band (the 8-GPU share) was 2.5 ms against 1.5 ms with
+ * one.  So: as few samples per item as the partial-sum workspace allows (12 B per item in f32). */
+#define MIRT_PARTIAL_BUDGET (1024ull << 20)
 static void choose_chunks(uint64_t n_pixels, uint32_t nsamples, size_t real_bytes, uint32_t* chunk, uint32_t* chunks) {
     uint64_t max_chunks = MIRT_PARTIAL_BUDGET / (std::max<uint64_t>(n_pixels, 1) * 3 * real_bytes);
     if (max_chunks < 1) max_chunks = 1;
-    uint32_t q = nsamples >= 8 ? 4u : 1u; /* 64 spp -> 16 items of 4 samples per pixel */
+    uint32_t q = 1u;
     if (const char* e = getenv("MIRT_CHUNK")) q = (uint32_t)std::max(1, atoi(e)); /* tuning knob */
     while ((nsamples + q - 1) / q > max_chunks) q *= 2;
     *chunk = q;

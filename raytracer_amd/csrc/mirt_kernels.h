@@ -326,6 +326,8 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
 /* acc = (acc << 1) | signbit(q) */
 #define MIRT_CONS_PUSH(s) acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(MIRT_CONS_QW(s)), 31)
 
+    float4 pre = {0.f, 0.f, 0.f, 0.f}; /* streaming mode: prefetched record of tile `pre_tile` */
+    uint32_t pre_tile = 0xFFFFFFFFu;
     uint32_t g = 0;
     while (g < ngroups) { /* one pass unless some lane's entry list fills up */
         uint32_t cnt = 0;
@@ -340,7 +342,12 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
             if (RES) {
                 tp = L.S + tile * MIRT_TILE;
             } else {
-                L.S[w * MIRT_TILE + lane] = sc.S[tile * MIRT_TILE + lane]; /* the array is padded to whole tiles */
+                /* one coalesced record per lane; the NEXT tile's record is already on its way from L2 while this one is
+                 * tested (the array is padded to whole tiles plus one spare, so tile + 1 always exists) */
+                if (pre_tile != tile) pre = sc.S[tile * MIRT_TILE + lane]; /* first tile of a pass, or resuming after a flush */
+                L.S[w * MIRT_TILE + lane] = pre;
+                pre = sc.S[(tile + 1) * MIRT_TILE + lane];
+                pre_tile = tile + 1;
                 tp = L.S + w * MIRT_TILE;
             }
             uint32_t gend = (tile + 1) * (MIRT_TILE / MIRT_CGROUP);
