@@ -79,12 +79,16 @@ template <> struct Draws<double> {
 template <> struct Draws<float> {
     uint32_t pixel, sample, bounce;
     uint64_t seed;
+    /* dims 0..3: the top 24 bits of words 0..3 of block 0; dim 4: the 24 bits left over in the low bytes of words
+     * 0..2 of the SAME block (a camera ray needs five draws and Philox is the dearest part of ray generation on the
+     * GPU: one block instead of two); dims >= 5: word (d-5)%4 of block 1 + (d-5)/4 */
     float dim(uint32_t d) const {
-        uint32_t c[4] = {pixel, sample, bounce, d / 4};
+        uint32_t c[4] = {pixel, sample, bounce, d < 5 ? 0u : 1u + (d - 5) / 4};
         uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
         uint32_t o[4];
         philox4x32_10(c, k, o);
-        return (float)(o[d % 4] >> 8) * 0x1.0p-24f;
+        if (d == 4) return (float)((o[0] & 0xFFu) | ((o[1] & 0xFFu) << 8) | ((o[2] & 0xFFu) << 16)) * 0x1.0p-24f;
+        return (float)(o[d < 5 ? d : (d - 5) % 4] >> 8) * 0x1.0p-24f;
     }
 };
 

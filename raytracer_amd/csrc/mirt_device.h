@@ -150,8 +150,9 @@ __host__ __device__ inline uint32_t part_global_row(const DevPart& p, uint32_t l
 /* ---- counter-based RNG: Philox4x32-10 (Salmon et al., SC'11) --------------------------------------
  * ctr = (pixel, sample, bounce, block), key = (seed_lo, seed_hi).  Dimension d of a stream (pixel, sample, bounce):
  *   f64: block d/2, 64-bit word pair d%2 (x0|x1<<32, x2|x3<<32), u = (word >> 11) * 2^-53
- *   f32: block d/4, 32-bit word d%4,                             u = (word >> 8)  * 2^-24
- * (Philox's integer multiplies are quarter-rate on the VALU: the f32 mode gets four draws out of one block.) */
+ *   f32: block 0: dims 0..3 = (word d >> 8) * 2^-24, dim 4 = the low bytes of words 0..2 (24 bits) * 2^-24
+ * (Philox's integer multiplies are quarter-rate on the VALU: the f32 mode gets all five draws of a camera ray, or the
+ * four of a bounce, out of one block.) */
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -182,8 +183,12 @@ template <> struct Draws<double> {
         b = (double)(((uint64_t)o[2] | ((uint64_t)o[3] << 32)) >> 11) * 0x1.0p-53;
     }
     __device__ inline void dims0123(double& a, double& b, double& c, double& d) const { pair(0, a, b); pair(1, c, d); }
-    __device__ inline double dim0() const { double a, b; pair(0, a, b); return a; }
-    __device__ inline double dim4() const { double a, b; pair(2, a, b); return a; }
+    __device__ inline void dims01234(double& a, double& b, double& c, double& d, double& e) const {
+        double f;
+        pair(0, a, b);
+        pair(1, c, d);
+        pair(2, e, f);
+    }
 };
 template <> struct Draws<float> {
     uint32_t pixel, sample, bounce, k0, k1;
@@ -193,11 +198,12 @@ template <> struct Draws<float> {
         philox4x32_10(pixel, sample, bounce, 0u, k0, k1, o);
         a = cvt(o[0]); b = cvt(o[1]); c = cvt(o[2]); d = cvt(o[3]);
     }
-    __device__ inline float dim0() const { float a, b, c, d; dims0123(a, b, c, d); return a; }
-    __device__ inline float dim4() const {
+    /* dims 0..4 out of ONE block: dim 4 = the low bytes of words 0..2 (24 bits) */
+    __device__ inline void dims01234(float& a, float& b, float& c, float& d, float& e) const {
         uint32_t o[4];
-        philox4x32_10(pixel, sample, bounce, 1u, k0, k1, o);
-        return cvt(o[0]);
+        philox4x32_10(pixel, sample, bounce, 0u, k0, k1, o);
+        a = cvt(o[0]); b = cvt(o[1]); c = cvt(o[2]); d = cvt(o[3]);
+        e = (float)((o[0] & 0xFFu) | ((o[1] & 0xFFu) << 8) | ((o[2] & 0xFFu) << 16)) * 0x1.0p-24f;
     }
 };
 

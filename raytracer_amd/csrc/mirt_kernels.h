@@ -265,10 +265,17 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
  *     material ids for the narrow phase and the hit record; nothing about a sphere is read from HBM in the loop
  *   larger scenes: wave w stages 64-record tiles of S in S[64 w .. 64 w + 63]; A, B, material come from HBM/L2
  *   ent: per-wave, per-lane entry lists (group number << 16 | inverted sign bits) */
+#ifndef MIRT_F32_WAVES
 #define MIRT_F32_WAVES 16
+#endif
+#ifndef MIRT_F32_EU
+#define MIRT_F32_EU 4 /* waves per SIMD the render kernel is compiled for (VGPR budget = 512 / this) */
+#endif
 #define MIRT_F32_BLOCK (MIRT_F32_WAVES * MIRT_WAVE)
 #define MIRT_LDS_RECORDS 1024
+#ifndef MIRT_ENT_CAP
 #define MIRT_ENT_CAP 16
+#endif
 struct F32Lds {
     float4 S[MIRT_LDS_RECORDS];
     float4 A[MIRT_LDS_RECORDS];
@@ -556,8 +563,8 @@ __device__ inline bool scatter(const DevScene<R>& sc, uint32_t mat, const RayT<R
 
 /* ---- camera rays: camera/camera.rs:209-230, 248-252, 261-264 --------------------------------------- */
 template <class R> __device__ inline RayT<R> ray_for(const DevCamera<R>& c, uint32_t wn, uint32_t hn, const Draws<R>& dr) {
-    R ua, ub, uc, ud; /* dims 0,1 = anti-aliasing offsets, 2,3 = lens disk (r, theta), 4 = shutter time */
-    dr.dims0123(ua, ub, uc, ud);
+    R ua, ub, uc, ud, ue; /* dims 0,1 = anti-aliasing offsets, 2,3 = lens disk (r, theta), 4 = shutter time */
+    dr.dims01234(ua, ub, uc, ud, ue);
     R ox = ua - (R)0.5, oy = ub - (R)0.5;
     V3<R> px = c.px00 + (c.du * ((R)wn + ox)) + (c.dv * ((R)hn + oy));
     V3<R> orig = c.lookfrom;
@@ -568,7 +575,7 @@ template <class R> __device__ inline RayT<R> ray_for(const DevCamera<R>& c, uint
         R dx = r * m_cos(th), dy = r * m_sin(th);
         orig = c.lookfrom + (c.disk_u * dx) + (c.disk_v * dy);
     }
-    return {orig, px - orig, dr.dim4()};
+    return {orig, px - orig, ue};
 }
 template <class R> __device__ inline RayT<R> primary_ray(const DevCamera<R>& c, uint32_t wn, uint32_t hn) {
     V3<R> pc = c.ul + (c.du * (R)wn) + (c.dv * (R)hn);
@@ -841,7 +848,7 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel_f64(DevSc
     render_body(tr, sc, cam, part, rp, partial, stats, lane);
 }
 /* one block of 16 waves per CU: 4 waves per SIMD, <= 128 VGPRs */
-__global__ __launch_bounds__(MIRT_F32_BLOCK) void render_kernel_f32(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
+__global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
                                                                     float* __restrict__ partial, DevStats* __restrict__ stats) {
     __shared__ F32Lds L;
     const bool res = L.fill(sc);

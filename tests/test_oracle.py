@@ -24,13 +24,18 @@ def test_philox_kat(oracle, ctr, key, want):
 
 
 def test_draw_contract(oracle):
-    # f64: dim d = 64-bit word pair d%2 of block d/2, (u64 >> 11) * 2^-53;  f32: dim d = 32-bit word d%4 of block d/4, >> 8
+    # f64: dim d = 64-bit word pair d%2 of block d/2, (u64 >> 11) * 2^-53
+    # f32: block 0 serves dims 0..4: dims 0..3 = word d >> 8, dim 4 = the low bytes of words 0..2
     for d in range(6):
         o = oracle.philox([5, 6, 7, d // 2], [9, 0])
         u = (o[0] | (o[1] << 32)) if d % 2 == 0 else (o[2] | (o[3] << 32))
         assert oracle.draw_dim(9, 5, 6, 7, d, abi.F64) == (u >> 11) * 2.0**-53
-        o = oracle.philox([5, 6, 7, d // 4], [9, 0])
-        assert oracle.draw_dim(9, 5, 6, 7, d, abi.F32) == (o[d % 4] >> 8) * 2.0**-24
+    o = oracle.philox([5, 6, 7, 0], [9, 0])
+    for d in range(4):
+        assert oracle.draw_dim(9, 5, 6, 7, d, abi.F32) == (o[d] >> 8) * 2.0**-24
+    assert oracle.draw_dim(9, 5, 6, 7, 4, abi.F32) == ((o[0] & 0xFF) | ((o[1] & 0xFF) << 8) | ((o[2] & 0xFF) << 16)) * 2.0**-24
+    o1 = oracle.philox([5, 6, 7, 1], [9, 0])
+    assert oracle.draw_dim(9, 5, 6, 7, 5, abi.F32) == (o1[0] >> 8) * 2.0**-24
     vals = [oracle.draw_dim(3, 1, s, 0, d, p) for s in range(50) for d in range(5) for p in (abi.F64, abi.F32)]
     assert all(0.0 <= v < 1.0 for v in vals) and 0.4 < sum(vals) / len(vals) < 0.6
 
