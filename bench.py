@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--accel", default="brute", choices=["brute", "bvh"], help="closest-hit method: the brute-force tile loop (the metric) or the bounding-ball tree")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets N ranks rehearse the N>1 path on ONE GPU")
     args = ap.parse_args()
 
@@ -119,7 +120,8 @@ def main():
     band = torch.zeros((rows0, W, 3), dtype=real, device="cuda")
     band8 = torch.zeros((rows0, W, 3), dtype=torch.uint8, device="cuda")
     frame = torch.zeros((H, W, 3), dtype=real, device="cuda") if rank == 0 else None
-    opts = cam.opts(precision=args.precision, seed=args.seed, strip_rows=S, part_index=rank, part_count=world, flags=abi.FLAG_COMPACT_ROWS)
+    opts = cam.opts(precision=args.precision, seed=args.seed, strip_rows=S, part_index=rank, part_count=world,
+                    flags=abi.FLAG_COMPACT_ROWS | (abi.FLAG_BVH if args.accel == "bvh" else 0))
     stream = torch.cuda.current_stream().cuda_stream
     elem = 3 * (4 if args.precision == 32 else 8)
 
@@ -181,6 +183,7 @@ def main():
                 "workload": f"{scene_name}: {scene.flat.n_spheres} spheres, {W}x{H}, {cam.pod.samples_per_pixel} spp, depth {cam.pod.max_bounce_depth}",
                 "parallelism": f"interleaved {S}-row strips over {world} GPU(s), RCCL all-gather of f32 RGB bands",
                 "seed": args.seed,
+                "closest_hit": "brute-force LDS tile loop" if args.accel == "brute" else "bounding-ball tree (MIRT_FLAG_BVH)",
             },
             "roofline": {
                 "bound": "valu_fp32",
@@ -189,7 +192,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
                 "traffic": None,
-                "kernel": "render_kernel_f32" if args.precision == 32 else "render_kernel_f64<2>",
+                "kernel": ("render_kernel_f32" if args.accel == "brute" else "render_kernel_f32_bvh") if args.precision == 32 else "render_kernel_f64<2>",
                 "kernel_ms_avg": round(kern_ms / max(1, len(stats)), 3),
                 "flops_per_segment": round(flops / max(seg, 1), 1),
                 "note": "algorithmic flops = 18/static sphere test + 27/moving sphere test + 5/segment (SURVEY.md 8d); rank 0's launches",

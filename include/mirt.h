@@ -119,6 +119,10 @@ typedef enum mirt_precision {
 } mirt_precision;
 
 #define MIRT_FLAG_COMPACT_ROWS 1u /* outputs hold only the rows this call owns, packed in row order */
+/* Closest hit through a bounding-ball tree built by mirt_scene_create instead of the brute-force tile loop (f32
+ * precision only).  Same (id, t) for every ray, hence the same image bit for bit; the counterpart of the reference's
+ * Bvh::hit (src/scene/bvh.rs:78-92) for scenes where testing every sphere is not affordable. */
+#define MIRT_FLAG_BVH 2u
 
 /* Which rows a call renders: rows are grouped in strips of `strip_rows`; strip s is owned when
  * s % part_count == part_index (interleaved strips).  part_count <= 1 = whole image. */

@@ -10,6 +10,7 @@ import os
 MISS_ID = 0xFFFFFFFF
 F64, F32 = 64, 32
 FLAG_COMPACT_ROWS = 1
+FLAG_BVH = 2  # closest hit through the bounding-ball tree (f32 only); same image bit for bit
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 

@@ -387,15 +387,16 @@ class Camera:
         )
 
     # -- the hot path: everything below runs in the HIP library -------------------------------------
-    def render_arrays(self, scene: Scene, precision=None, seed=None, want_linear=True, want_rgb8=True):
-        """Camera::render without the text emission: returns (linear (H,W,3) real | None, rgb8 (H,W,3) u8 | None)."""
+    def render_arrays(self, scene: Scene, precision=None, seed=None, want_linear=True, want_rgb8=True, accel=None):
+        """Camera::render without the text emission: returns (linear (H,W,3) real | None, rgb8 (H,W,3) u8 | None).
+        accel="bvh" traverses the bounding-ball tree (abi.FLAG_BVH, f32 only) instead of testing every sphere."""
         ds = scene.device_scene(self.device)
         prec = self.precision if precision is None else precision
         H, W = self.height, self.width
         lin = np.empty((H, W, 3), dtype=np.float64 if prec == abi.F64 else np.float32) if want_linear else None
         rgb8 = np.empty((H, W, 3), dtype=np.uint8) if want_rgb8 else None
         st = abi.MirtStats()
-        o = self.opts(precision=prec, seed=seed)
+        o = self.opts(precision=prec, seed=seed, flags=abi.FLAG_BVH if accel == "bvh" else 0)
         abi.check(
             abi.load().mirt_render(
                 ds.handle, C.byref(self.pod), C.byref(o),
@@ -405,14 +406,14 @@ class Camera:
         self.last_stats = st.asdict()
         return lin, rgb8
 
-    def primary_hits(self, scene: Scene, precision=None):
+    def primary_hits(self, scene: Scene, precision=None, accel=None):
         """Hit-id / t map of the deterministic branch (camera.rs:247-254)."""
         ds = scene.device_scene(self.device)
         prec = self.precision if precision is None else precision
         H, W = self.height, self.width
         ids = np.empty((H, W), dtype=np.uint32)
         t = np.empty((H, W), dtype=np.float64 if prec == abi.F64 else np.float32)
-        o = self.opts(precision=prec)
+        o = self.opts(precision=prec, flags=abi.FLAG_BVH if accel == "bvh" else 0)
         abi.check(abi.load().mirt_primary_hits(ds.handle, C.byref(self.pod), C.byref(o), ids.ctypes.data, t.ctypes.data))
         return ids, t
 

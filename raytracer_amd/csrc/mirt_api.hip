@@ -46,6 +46,11 @@ struct mirt_scene {
     SceneBuffers<double> f64;
     uint32_t *orig_id = nullptr, *material = nullptr, *texels = nullptr;
     float4* S = nullptr; /* f32 conservative broad-phase records */
+    BvhNode* bvh = nullptr; /* bounding-ball tree (MIRT_FLAG_BVH) */
+    float4* bvh_S = nullptr;
+    uint32_t* bvh_idx = nullptr;
+    uint32_t bvh_root = MIRT_BVH_NONE;
+    bool bvh_ok = false;
     DevImage* imgs = nullptr;
     DevStats* stats = nullptr; /* one per scene: calls on one scene handle are not re-entrant */
     std::vector<void*> allocs;
@@ -60,6 +65,109 @@ template <class T> static int upload(mirt_scene* s, const std::vector<T>& host, 
     HIP_TRY(hipMalloc((void**)dev, bytes));
     s->allocs.push_back(*dev);
     if (!host.empty()) HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MIRT_OK;
+}
+
+
+/* ---- bounding-ball tree (MIRT_FLAG_BVH) ---------------------------------------------------------------
+ * Leaves are runs of <= 8 bounding records (the same (M, w) records the brute-force broad phase tests, copied in leaf
+ * order); an inner node holds the enclosing ball of each child: centre = middle of the children's box of balls,
+ * rho = max_i (|M_i - M| + rho_i), then widened to R = rho + s (|M| + rho) for the rounding slack of the leaf test
+ * (trace_bvh has the derivation).  Median split on the longest axis of the centres: depth <= MIRT_BVH_STACK, which
+ * is what the traversal stack holds. */
+struct BallRec {
+    double M[3];
+    double rho;
+    uint32_t idx; /* sorted sphere index */
+};
+struct BvhBuild {
+    std::vector<BallRec>& b;
+    std::vector<BvhNode> nodes;
+    std::vector<float4> leafS;
+    std::vector<uint32_t> leafIdx;
+    const std::vector<float4>& S;
+    uint32_t leaf_size;
+    uint32_t depth_max = 0;
+
+    static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+    static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+    /* enclosing ball of b[lo, hi) -> (M, rho) */
+    void enclose(size_t lo, size_t hi, double M[3], double& rho) const {
+        double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+        for (size_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) {
+                mn[a] = std::min(mn[a], b[i].M[a] - b[i].rho);
+                mx[a] = std::max(mx[a], b[i].M[a] + b[i].rho);
+            }
+        float Mf[3];
+        for (int a = 0; a < 3; ++a) { Mf[a] = (float)(0.5 * (mn[a] + mx[a])); M[a] = Mf[a]; } /* the centre the kernel sees */
+        rho = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            double d2 = 0;
+            for (int a = 0; a < 3; ++a) d2 += (b[i].M[a] - M[a]) * (b[i].M[a] - M[a]);
+            rho = std::max(rho, std::sqrt(d2) + b[i].rho);
+        }
+        rho *= 1.0 + 1e-9;
+    }
+    /* child test record for the ball of b[lo, hi) and the reference `ref` */
+    void child_record(size_t lo, size_t hi, uint32_t ref, float4& m, float4& p) const {
+        const double eps = 1.0 / 16777216.0, s = (double)MIRT_BVH_S;
+        double M[3], rho;
+        enclose(lo, hi, M, rho);
+        double Ml = std::sqrt(M[0] * M[0] + M[1] * M[1] + M[2] * M[2]);
+        double R = rho + s * (Ml + rho);
+        double w = Ml * Ml - R * R - 160.0 * eps * (Ml * Ml + R * R);
+        float wf = (float)w;
+        if ((double)wf > w) wf = std::nextafterf(wf, -INFINITY);
+        wf = std::nextafterf(wf, -INFINITY);
+        float Rf = (float)(R * (1.0 + 1e-6));
+        if ((double)Rf < R) Rf = std::nextafterf(Rf, INFINITY);
+        float cf = (float)(2.0 * s * R * (1.0 + 1e-5));
+        m.x = (float)M[0]; m.y = (float)M[1]; m.z = (float)M[2]; m.w = wf;
+        p.x = cf; p.y = Rf; p.z = u2f(ref); p.w = 0.f;
+    }
+    /* builds the subtree of b[lo, hi), returns its ref */
+    uint32_t build(size_t lo, size_t hi, uint32_t depth) {
+        depth_max = std::max(depth_max, depth);
+        if (hi - lo <= leaf_size) {
+            uint32_t first = (uint32_t)leafS.size();
+            for (size_t i = lo; i < hi; ++i) { leafS.push_back(S[b[i].idx]); leafIdx.push_back(b[i].idx); }
+            return 0x80000000u | (first << 3) | (uint32_t)(hi - lo - 1);
+        }
+        double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+        for (size_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], b[i].M[a]); mx[a] = std::max(mx[a], b[i].M[a]); }
+        int ax = 0;
+        for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[ax] - mn[ax]) ax = a;
+        size_t mid = lo + (hi - lo) / 2;
+        std::nth_element(b.begin() + lo, b.begin() + mid, b.begin() + hi, [ax](const BallRec& x, const BallRec& y) {
+            return x.M[ax] < y.M[ax] || (x.M[ax] == y.M[ax] && x.idx < y.idx);
+        });
+        uint32_t me = (uint32_t)nodes.size();
+        nodes.push_back(BvhNode{});
+        uint32_t l = build(lo, mid, depth + 1), r = build(mid, hi, depth + 1);
+        BvhNode nd;
+        child_record(lo, mid, l, nd.m[0], nd.p[0]);
+        child_record(mid, hi, r, nd.m[1], nd.p[1]);
+        nodes[me] = nd;
+        return me;
+    }
+};
+static int build_bvh(mirt_scene* s, std::vector<BallRec>& balls, const std::vector<float4>& S) {
+    s->bvh_ok = false;
+    s->bvh_root = MIRT_BVH_NONE;
+    if (balls.empty()) { s->bvh_ok = true; return MIRT_OK; } /* empty scene: every ray misses */
+    if (balls.size() >= (1u << 27)) return MIRT_OK;          /* leaf refs hold 28 bits of record index: no tree, flag rejected */
+    uint32_t leaf = 4;
+    while (leaf < 8 && ((balls.size() + leaf - 1) / leaf) > (1ull << MIRT_BVH_STACK)) ++leaf;
+    BvhBuild bb{balls, {}, {}, {}, S, leaf};
+    uint32_t root = bb.build(0, balls.size(), 0);
+    if (bb.depth_max > MIRT_BVH_STACK) return MIRT_OK; /* deeper than the traversal stack: MIRT_FLAG_BVH is refused for this scene */
+    bb.leafS.push_back(float4{0.f, 0.f, 0.f, INFINITY}); /* leaf reads fetch whole pairs */
+    int rc;
+    if ((rc = upload(s, bb.nodes, &s->bvh)) || (rc = upload(s, bb.leafS, &s->bvh_S)) || (rc = upload(s, bb.leafIdx, &s->bvh_idx))) return rc;
+    s->bvh_root = root;
+    s->bvh_ok = true;
     return MIRT_OK;
 }
 
@@ -113,6 +221,7 @@ template <class R> static DevScene<R> dev_scene(const mirt_scene* s, const Scene
     d.imgs = s->imgs; d.texels = s->texels; d.n = s->n; d.n_static = s->n_static;
     d.S = sizeof(R) == 4 ? s->S : nullptr;
     d.n_materials = s->n_materials;
+    d.bvh = s->bvh; d.bvh_S = s->bvh_S; d.bvh_idx = s->bvh_idx; d.bvh_root = s->bvh_root;
     d.dbg = s->stats ? &s->stats->broad_misses : nullptr;
     return d;
 }
@@ -139,6 +248,10 @@ static int check_common(const mirt_scene* s, const mirt_camera* cam, const mirt_
     if (o->precision != MIRT_F32 && o->precision != MIRT_F64) return fail(MIRT_ERR_INVALID, "mirt_opts.precision must be 32 or 64");
     if (cam->img_width == 0 || cam->img_height == 0) return fail(MIRT_ERR_INVALID, "empty image");
     if ((uint64_t)cam->img_width * cam->img_height > 0xFFFFFFFFull) return fail(MIRT_ERR_TOO_LARGE, "W*H must fit 32 bits (RNG pixel counter)");
+    if (o->flags & MIRT_FLAG_BVH) {
+        if (o->precision != MIRT_F32) return fail(MIRT_ERR_INVALID, "MIRT_FLAG_BVH is an f32-mode accelerator (precision must be MIRT_F32)");
+        if (!s->bvh_ok) return fail(MIRT_ERR_TOO_LARGE, "scene too large for the bounding-ball tree (depth or record limit)");
+    }
     return MIRT_OK;
 }
 static uint32_t grid_for(uint32_t W, uint32_t local_rows, uint32_t waves_per_block) {
@@ -156,10 +269,13 @@ static int launch_primary(const mirt_scene* s, const SceneBuffers<double>& b, co
     return MIRT_OK;
 }
 static int launch_primary(const mirt_scene* s, const SceneBuffers<float>& b, const mirt_camera* cam, const DevPart& part, uint32_t* d_id, void* d_t,
-                          hipStream_t st) {
-    uint32_t grid = grid_for(cam->img_width, part.local_rows, MIRT_F32_WAVES);
+                          hipStream_t st, bool bvh = false) {
+    uint32_t grid = grid_for(cam->img_width, part.local_rows, bvh ? MIRT_WAVES_PER_BLOCK : MIRT_F32_WAVES);
     if (grid == 0) return MIRT_OK;
-    hipLaunchKernelGGL(primary_hits_kernel_f32, dim3(grid), dim3(MIRT_F32_BLOCK), 0, st, dev_scene<float>(s, b), dev_camera<float>(cam), part, d_id, (float*)d_t);
+    if (bvh)
+        hipLaunchKernelGGL(primary_hits_kernel_f32_bvh, dim3(grid), dim3(MIRT_BLOCK), 0, st, dev_scene<float>(s, b), dev_camera<float>(cam), part, d_id, (float*)d_t);
+    else
+        hipLaunchKernelGGL(primary_hits_kernel_f32, dim3(grid), dim3(MIRT_F32_BLOCK), 0, st, dev_scene<float>(s, b), dev_camera<float>(cam), part, d_id, (float*)d_t);
     HIP_TRY(hipGetLastError());
     return MIRT_OK;
 }
@@ -179,21 +295,22 @@ static void choose_chunks(uint64_t n_pixels, uint32_t nsamples, size_t real_byte
 }
 
 /* the two render kernels behind one name */
-static const void* render_fn(double) { return (const void*)render_kernel_f64<2>; }
-static const void* render_fn(float) { return (const void*)render_kernel_f32; }
-static void launch_render_kernel(uint32_t grid, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam, const DevPart& part,
-                                 const RenderParams& rp, double* partial, DevStats* stats) {
-    hipLaunchKernelGGL(render_kernel_f64<2>, dim3(grid), dim3(MIRT_BLOCK), 0, st, sc, cam, part, rp, partial, stats);
+static const void* render_fn(double, bool) { return (const void*)render_kernel_f64<2>; }
+static const void* render_fn(float, bool bvh) { return bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
+static void launch_render_kernel(uint32_t grid, uint32_t block, bool, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam,
+                                 const DevPart& part, const RenderParams& rp, double* partial, DevStats* stats) {
+    hipLaunchKernelGGL(render_kernel_f64<2>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
 }
-static void launch_render_kernel(uint32_t grid, hipStream_t st, const DevScene<float>& sc, const DevCamera<float>& cam, const DevPart& part,
-                                 const RenderParams& rp, float* partial, DevStats* stats) {
-    hipLaunchKernelGGL(render_kernel_f32, dim3(grid), dim3(MIRT_F32_BLOCK), 0, st, sc, cam, part, rp, partial, stats);
+static void launch_render_kernel(uint32_t grid, uint32_t block, bool bvh, hipStream_t st, const DevScene<float>& sc, const DevCamera<float>& cam,
+                                 const DevPart& part, const RenderParams& rp, float* partial, DevStats* stats) {
+    if (bvh) hipLaunchKernelGGL(render_kernel_f32_bvh, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    else hipLaunchKernelGGL(render_kernel_f32, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
 }
 
 template <class R>
 static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mirt_camera* cam, const DevPart& part, uint64_t seed, void* d_lin,
-                         uint8_t* d_rgb8, hipStream_t st) {
-    const uint32_t block = sizeof(R) == 4 ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;
+                         uint8_t* d_rgb8, hipStream_t st, bool bvh) {
+    const uint32_t block = (sizeof(R) == 4 && !bvh) ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;
     uint64_t n_pixels = (uint64_t)cam->img_width * part.local_rows;
     if (n_pixels == 0) return MIRT_OK;
     RenderParams rp;
@@ -221,13 +338,13 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     } else {
         /* persistent grid: as many blocks as can be resident, every wave pulls items until the queue is empty */
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_fn(R()), (int)block, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_fn(R(), bvh), (int)block, 0));
         if (per_cu < 1) per_cu = 1;
         uint64_t waves_needed = ((uint64_t)rp.n_items + 63) / 64;
         uint64_t grid = std::min<uint64_t>((uint64_t)s->n_cus * per_cu, (waves_needed + waves_per_block - 1) / waves_per_block);
         /* the last two full batches per wave are handed out one item per lane at a time */
         rp.tail_items = (uint32_t)std::min<uint64_t>(grid * waves_per_block * 2 * MIRT_QUEUE_BATCH, rp.n_items);
-        launch_render_kernel((uint32_t)grid, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, rp, (R*)s->partial, s->stats);
+        launch_render_kernel((uint32_t)grid, block, bvh, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, rp, (R*)s->partial, s->stats);
         HIP_TRY(hipGetLastError());
     }
     uint32_t rgrid = (uint32_t)((n_pixels + 255) / 256);
@@ -323,6 +440,8 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
         std::vector<float4> S((order.size() + MIRT_TILE - 1) / MIRT_TILE * MIRT_TILE + MIRT_TILE); /* whole tiles + one spare */
         for (size_t k = order.size(); k < S.size(); ++k) { S[k].x = S[k].y = S[k].z = 0.f; S[k].w = INFINITY; }
         const double eps = 1.0 / 16777216.0; /* 2^-24 */
+        std::vector<BallRec> balls; /* real spheres only, for the bounding-ball tree */
+        balls.reserve(d->n_spheres);
         for (size_t k = 0; k < order.size(); ++k) {
             if (order[k] == 0xFFFFFFFFu) { S[k].x = S[k].y = S[k].z = 0.f; S[k].w = INFINITY; continue; }
             const mirt_sphere& sp = d->spheres[order[k]];
@@ -347,8 +466,10 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
             if ((double)wf > w) wf = std::nextafterf(wf, -INFINITY); /* round toward the conservative side */
             wf = std::nextafterf(wf, -INFINITY);
             S[k].x = Mf[0]; S[k].y = Mf[1]; S[k].z = Mf[2]; S[k].w = wf;
+            balls.push_back(BallRec{{(double)Mf[0], (double)Mf[1], (double)Mf[2]}, rho, (uint32_t)k});
         }
         if ((rc = upload(s, S, &s->S))) { mirt_scene_destroy(s); return rc; }
+        if ((rc = build_bvh(s, balls, S))) { mirt_scene_destroy(s); return rc; }
     }
     std::vector<DevStats> st(1);
     memset(st.data(), 0, sizeof(DevStats));
@@ -374,7 +495,7 @@ int mirt_primary_hits_device(const mirt_scene* s, const mirt_camera* cam, const 
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     return o->precision == MIRT_F64 ? launch_primary(s, s->f64, cam, part, d_id, d_t, st)
-                                    : launch_primary(s, s->f32, cam, part, d_id, d_t, st);
+                                    : launch_primary(s, s->f32, cam, part, d_id, d_t, st, (o->flags & MIRT_FLAG_BVH) != 0);
 }
 
 int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, void* d_lin, uint8_t* d_rgb8, void* stream,
@@ -392,8 +513,8 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    rc = o->precision == MIRT_F64 ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st)
-                                  : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st);
+    rc = o->precision == MIRT_F64 ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st, false)
+                                  : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0);
     if (stats) {
         if (!rc) {
             hipError_t e = hipEventRecord(e1, st);

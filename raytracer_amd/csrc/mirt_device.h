@@ -83,6 +83,18 @@ template <class R> struct DevMaterial {
     R reflectance, fuzz, ior;
     V3<R> albedo;
 };
+/* Node of the bounding-ball tree (MIRT_FLAG_BVH): the test data of BOTH children, one 64-byte fetch per step.
+ *   m  = (M.x, M.y, M.z, w)   centre of the child's ball, w = |M|^2 - R^2 - 160 eps (|M|^2 + R^2)
+ *   p  = (c, R, ref, -)       c = 2 s R, R = rho + s (|M| + rho) with s = MIRT_BVH_S: see trace_bvh
+ *   ref (bit pattern in p.z): bit 31 set = leaf, bits 3..30 first record, bits 0..2 count - 1; clear = node index;
+ *                             0xFFFFFFFF = no child */
+struct BvhNode {
+    float4 m[2], p[2];
+};
+#define MIRT_BVH_S 4.0e-3f
+#define MIRT_BVH_NONE 0xFFFFFFFFu
+#define MIRT_BVH_STACK 16
+
 template <class R> struct DevScene {
     /* spheres, statics first: [0, n_static) static, [n_static, n) moving; both counts are padded to a
      * multiple of MIRT_GROUP with dummy records (r*r = -inf -> never a candidate, orig_id = ~0u) */
@@ -101,6 +113,11 @@ template <class R> struct DevScene {
     unsigned long long* dbg;         /* diagnostic builds: counter of broad-phase misses (must stay 0) */
     uint32_t n, n_static;
     uint32_t n_materials;
+    /* bounding-ball tree (f32 only): nodes, the bounding records in leaf order, leaf slot -> sorted sphere index */
+    const BvhNode* bvh;
+    const float4* bvh_S;
+    const uint32_t* bvh_idx;
+    uint32_t bvh_root; /* a ref like BvhNode::p.z */
 };
 template <class R> struct DevCamera { /* struct Camera, camera/camera.rs:107-120, rounded once to Real */
     V3<R> lookfrom, du, dv, ul, px00, disk_u, disk_v;

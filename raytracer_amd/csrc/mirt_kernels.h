@@ -421,6 +421,90 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
 #undef MIRT_CONS_PUSH
 }
 
+/* ---- f32, MIRT_FLAG_BVH: closest hit through the bounding-ball tree -----------------------------------
+ * Per-lane stack traversal (stack in LDS, one entry per level) of the tree built by mirt_scene_create; the leaves
+ * hold the same (M, w) bounding records as the brute-force broad phase and are tested with the same expression, the
+ * survivors go through the same exact narrow_test: the result is the brute-force result, sphere for sphere.
+ *
+ * Why a node may be skipped.  The leaf test is conservative for the exact test (trace_cons), and it passes only if the
+ * real line comes within sqrt(rho_i^2 + G_i) <= rho_i + sqrt(G_i) of M_i, where G_i <= 240 eps (|M_i| + rho_i + |O|)^2
+ * collects its margins and evaluation error, i.e. sqrt(G_i) <= s (|M_i| + rho_i + |O|) with s = MIRT_BVH_S = 4e-3
+ * >= 15.5 sqrt(eps).  A node ball (M_n, rho_n) encloses its leaf balls, so |M_i| + rho_i <= |M_n| + rho_n and the line
+ * comes within  rho_n + s (|M_n| + rho_n) + s |O| = R_n + s |O|  of M_n.  Squared and expanded like the leaf test:
+ *     q_n = h^2 + 2 O.M_n - |O|^2 (1 - s^2) - (|M_n|^2 - R_n^2) + 2 s R_n |O|  >=  0
+ * with the same 160 eps margins for its own evaluation (folded into w_n and the shrink of |O|^2): 10 VALU per child.
+ * The exact root t of any sphere under the node puts the point O + t D within R_n + s |O| of M_n as well (its error is
+ * <= 3.3 sqrt(eps) max(|C - O|, |C|)), so with u = R_n + s |O| and tau = t |D|:
+ *     h + u < 0          the whole ball is behind the origin    -> no root > tmin > 0 in it
+ *     h - u > tau_best   the whole ball is beyond the best hit  -> no root < best.t in it (ties are not beyond) */
+#define MIRT_NODE_SHRINK 0.99997f /* <= 1 - 160 eps - s^2 (1 + 1e-3) */
+__device__ inline void trace_bvh(const DevScene<float>& sc, uint32_t (*stk)[MIRT_WAVE], uint32_t lane, bool active, const RayT<float>& ray, float tmin,
+                                 Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+    best.t = INFINITY;
+    best.idx = 0xFFFFFFFFu;
+    const V3<float> O = ray.o;
+    const float a_true = ray_a(ray.d);
+    const float len = sqrtf(a_true);
+    const float inv = 1.0f / len;
+    const V3<float> Dn = {ray.d.x * inv, ray.d.y * inv, ray.d.z * inv};
+    const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
+    const float o2 = __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x));
+    const float nk2 = -(o2 * MIRT_RAY_SHRINK), nk2n = -(o2 * MIRT_NODE_SHRINK);
+    const float o1 = sqrtf(o2) * 1.000001f;
+    const V3<float> O2 = {O.x * 2.0f, O.y * 2.0f, O.z * 2.0f};
+    const float len_up = len * 1.00001f;
+    float tau_best = INFINITY;
+    uint32_t cur = active ? sc.bvh_root : MIRT_BVH_NONE, sp = 0;
+    while (__ballot(cur != MIRT_BVH_NONE) != 0ull) {
+        if (cur != MIRT_BVH_NONE) {
+            if (cur & 0x80000000u) { /* leaf: the conservative record test, then the exact test */
+                const uint32_t first = (cur >> 3) & 0x0FFFFFFFu, cnt = (cur & 7u) + 1u;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const float4 m = sc.bvh_S[first + k];
+                    const float h = __builtin_fmaf(Dn.z, m.z, __builtin_fmaf(Dn.y, m.y, __builtin_fmaf(Dn.x, m.x, -k1)));
+                    const float q = __builtin_fmaf(h, h, __builtin_fmaf(O2.z, m.z, __builtin_fmaf(O2.y, m.y, __builtin_fmaf(O2.x, m.x, nk2 - m.w))));
+                    if (q >= 0.0f) {
+                        narrow_test(sc, GeomGlobal<float>{sc}, sc.bvh_idx[first + k], ray, a_true, tmin, best);
+                        ++narrow_count;
+                    }
+                }
+                tau_best = best.t * len_up;
+                cur = MIRT_BVH_NONE;
+                if (sp > 0) cur = stk[--sp][lane];
+            } else {
+                const BvhNode& nd = sc.bvh[cur];
+                float hh[2];
+                bool pass[2];
+                uint32_t ref[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float4 m = nd.m[c], p = nd.p[c];
+                    ref[c] = __float_as_uint(p.z);
+                    const float h = __builtin_fmaf(Dn.z, m.z, __builtin_fmaf(Dn.y, m.y, __builtin_fmaf(Dn.x, m.x, -k1)));
+                    const float e = __builtin_fmaf(O2.z, m.z, __builtin_fmaf(O2.y, m.y, __builtin_fmaf(O2.x, m.x, nk2n - m.w)));
+                    const float q = __builtin_fmaf(h, h, __builtin_fmaf(p.x, o1, e));
+                    const float u = __builtin_fmaf(MIRT_BVH_S, o1, p.y) * 1.001f;
+                    hh[c] = h;
+                    pass[c] = q >= 0.0f && h + u >= 0.0f && h - u <= tau_best;
+                }
+                const bool swap = hh[1] < hh[0]; /* nearer centre first */
+                const uint32_t r_near = swap ? ref[1] : ref[0], r_far = swap ? ref[0] : ref[1];
+                const bool p_near = swap ? pass[1] : pass[0], p_far = swap ? pass[0] : pass[1];
+                if (p_near) {
+                    cur = r_near;
+                    if (p_far) stk[sp++][lane] = r_far; /* depth <= MIRT_BVH_STACK, checked at build time */
+                } else if (p_far) {
+                    cur = r_far;
+                } else {
+                    cur = MIRT_BVH_NONE;
+                    if (sp > 0) cur = stk[--sp][lane];
+                }
+            }
+        }
+    }
+    pt.stamp(PH_BROAD);
+}
+
 /* ---- hit record of the winner: sphere.rs:102-107, hittable.rs:48-60 -------------------------------- */
 template <class R> struct Hit {
     V3<R> p, n, on; /* on = outward normal (input of Sphere::uv) */
@@ -463,6 +547,17 @@ template <bool RES> struct TracerF32 {
         return make_hit(sc, GeomGlobal<float>{sc}, c, ray);
     }
     __device__ inline uint32_t material(uint32_t idx) const { return RES ? (uint32_t)L.mat[idx] : sc.material[idx]; }
+};
+
+struct TracerF32Bvh {
+    typedef float Real;
+    const DevScene<float>& sc;
+    uint32_t (*stk)[MIRT_WAVE];
+    __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
+        trace_bvh(sc, stk, lane, active, ray, tmin, best, nc, pt);
+    }
+    __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const { return make_hit(sc, GeomGlobal<float>{sc}, c, ray); }
+    __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }
 };
 
 /* ---- textures: scene/texture.rs ----------------------------------------------------------------- */
@@ -672,6 +767,14 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK) void primary_hits_kernel_f32(DevSce
     }
 }
 
+__global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel_f32_bvh(DevScene<float> sc, DevCamera<float> cam, DevPart part, uint32_t* __restrict__ out_id,
+                                                                          float* __restrict__ out_t) {
+    __shared__ uint32_t stk[MIRT_WAVES_PER_BLOCK][MIRT_BVH_STACK][MIRT_WAVE];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    TracerF32Bvh tr{sc, stk[w]};
+    primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_WAVES_PER_BLOCK + w, lane, out_id, out_t);
+}
+
 /* ---- K2: persistent waves pulling work items from a queue --------------------------------------------
  * Work item = (pixel of this rank's band, chunk of `chunk` consecutive samples).  A LANE owns an item: it
  * runs the item's samples one after the other (regenerating its next camera ray the moment a path ends,
@@ -845,6 +948,14 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel_f64(DevSc
     __shared__ WaveLds<double> lds_all[MIRT_WAVES_PER_BLOCK];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     TracerF64 tr{sc, lds_all[w]};
+    render_body(tr, sc, cam, part, rp, partial, stats, lane);
+}
+/* MIRT_FLAG_BVH: latency-bound per-lane traversal, small blocks, as many waves as the registers allow */
+__global__ __launch_bounds__(MIRT_BLOCK) void render_kernel_f32_bvh(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
+                                                                    float* __restrict__ partial, DevStats* __restrict__ stats) {
+    __shared__ uint32_t stk[MIRT_WAVES_PER_BLOCK][MIRT_BVH_STACK][MIRT_WAVE];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    TracerF32Bvh tr{sc, stk[w]};
     render_body(tr, sc, cam, part, rp, partial, stats, lane);
 }
 /* one block of 16 waves per CU: 4 waves per SIMD, <= 128 VGPRs */
