@@ -69,16 +69,31 @@ template <class T> static int upload(mirt_scene* s, const std::vector<T>& host, 
 }
 
 
-/* ---- bounding-ball tree (MIRT_FLAG_BVH) ---------------------------------------------------------------
- * Leaves are runs of <= 8 bounding records (the same (M, w) records the brute-force broad phase tests, copied in leaf
- * order); an inner node holds the enclosing ball of each child: centre = middle of the children's box of balls,
- * rho = max_i (|M_i - M| + rho_i), then widened to R = rho + s (|M| + rho) for the rounding slack of the leaf test
- * (trace_bvh has the derivation).  Median split on the longest axis of the centres: depth <= MIRT_BVH_STACK, which
- * is what the traversal stack holds. */
+/* ---- bounding-volume tree (MIRT_FLAG_BVH) -------------------------------------------------------------
+ * Leaves are runs of <= 4 bounding records (the same (M, w) records the brute-force broad phase tests, copied in leaf
+ * order); an inner node holds the axis-aligned box of each child's bounding balls, widened by the constant part of
+ * the rounding slack of the leaf test (trace_bvh has the derivation).  Built top-down with a binned surface-area
+ * heuristic on the ball centres; when the remaining stack depth would not fit a balanced subtree, the split falls
+ * back to the median, so the depth never exceeds MIRT_BVH_STACK - which is what the traversal stack holds. */
 struct BallRec {
     double M[3];
     double rho;
     uint32_t idx; /* sorted sphere index */
+};
+struct BvhBox {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, A = 0; /* A = max (|M| + rho) */
+    void add(const BallRec& b) {
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.M[a] - b.rho); hi[a] = std::max(hi[a], b.M[a] + b.rho); }
+        A = std::max(A, std::sqrt(b.M[0] * b.M[0] + b.M[1] * b.M[1] + b.M[2] * b.M[2]) + b.rho);
+    }
+    void add(const BvhBox& o) {
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], o.lo[a]); hi[a] = std::max(hi[a], o.hi[a]); }
+        A = std::max(A, o.A);
+    }
+    double area() const {
+        double d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        return d[0] < 0 ? 0.0 : 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+    }
 };
 struct BvhBuild {
     std::vector<BallRec>& b;
@@ -89,66 +104,97 @@ struct BvhBuild {
     uint32_t leaf_size;
     uint32_t depth_max = 0;
 
-    static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
     static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-    /* enclosing ball of b[lo, hi) -> (M, rho) */
-    void enclose(size_t lo, size_t hi, double M[3], double& rho) const {
-        double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-        for (size_t i = lo; i < hi; ++i)
-            for (int a = 0; a < 3; ++a) {
-                mn[a] = std::min(mn[a], b[i].M[a] - b[i].rho);
-                mx[a] = std::max(mx[a], b[i].M[a] + b[i].rho);
-            }
-        float Mf[3];
-        for (int a = 0; a < 3; ++a) { Mf[a] = (float)(0.5 * (mn[a] + mx[a])); M[a] = Mf[a]; } /* the centre the kernel sees */
-        rho = 0;
-        for (size_t i = lo; i < hi; ++i) {
-            double d2 = 0;
-            for (int a = 0; a < 3; ++a) d2 += (b[i].M[a] - M[a]) * (b[i].M[a] - M[a]);
-            rho = std::max(rho, std::sqrt(d2) + b[i].rho);
-        }
-        rho *= 1.0 + 1e-9;
+    static float down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -INFINITY); return f; }
+    static float up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, INFINITY); return f; }
+    /* widened box of b[lo, hi) as the kernel sees it */
+    void child_box(size_t lo, size_t hi, float o_lo[3], float o_hi[3]) const {
+        BvhBox bx;
+        for (size_t i = lo; i < hi; ++i) bx.add(b[i]);
+        const double wd = (double)MIRT_BVH_S * bx.A * (1.0 + 1e-6);
+        for (int a = 0; a < 3; ++a) { o_lo[a] = down(bx.lo[a] - wd); o_hi[a] = up(bx.hi[a] + wd); }
     }
-    /* child test record for the ball of b[lo, hi) and the reference `ref` */
-    void child_record(size_t lo, size_t hi, uint32_t ref, float4& m, float4& p) const {
-        const double eps = 1.0 / 16777216.0, s = (double)MIRT_BVH_S;
-        double M[3], rho;
-        enclose(lo, hi, M, rho);
-        double Ml = std::sqrt(M[0] * M[0] + M[1] * M[1] + M[2] * M[2]);
-        double R = rho + s * (Ml + rho);
-        double w = Ml * Ml - R * R - 160.0 * eps * (Ml * Ml + R * R);
-        float wf = (float)w;
-        if ((double)wf > w) wf = std::nextafterf(wf, -INFINITY);
-        wf = std::nextafterf(wf, -INFINITY);
-        float Rf = (float)(R * (1.0 + 1e-6));
-        if ((double)Rf < R) Rf = std::nextafterf(Rf, INFINITY);
-        float cf = (float)(2.0 * s * R * (1.0 + 1e-5));
-        m.x = (float)M[0]; m.y = (float)M[1]; m.z = (float)M[2]; m.w = wf;
-        p.x = cf; p.y = Rf; p.z = u2f(ref); p.w = 0.f;
+    static uint32_t levels_for(size_t n, uint32_t leaf) { /* depth of a median-split subtree over n records */
+        uint32_t l = 0;
+        while (n > leaf) { n = (n + 1) / 2; ++l; }
+        return l;
     }
     /* builds the subtree of b[lo, hi), returns its ref */
     uint32_t build(size_t lo, size_t hi, uint32_t depth) {
         depth_max = std::max(depth_max, depth);
-        if (hi - lo <= leaf_size) {
+        const size_t n = hi - lo;
+        if (n <= leaf_size) {
             uint32_t first = (uint32_t)leafS.size();
             for (size_t i = lo; i < hi; ++i) { leafS.push_back(S[b[i].idx]); leafIdx.push_back(b[i].idx); }
-            return 0x80000000u | (first << 3) | (uint32_t)(hi - lo - 1);
+            return 0x80000000u | (first << 3) | (uint32_t)(n - 1);
         }
         double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
         for (size_t i = lo; i < hi; ++i)
             for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], b[i].M[a]); mx[a] = std::max(mx[a], b[i].M[a]); }
+        size_t mid = lo + n / 2;
         int ax = 0;
         for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[ax] - mn[ax]) ax = a;
-        size_t mid = lo + (hi - lo) / 2;
-        std::nth_element(b.begin() + lo, b.begin() + mid, b.begin() + hi, [ax](const BallRec& x, const BallRec& y) {
-            return x.M[ax] < y.M[ax] || (x.M[ax] == y.M[ax] && x.idx < y.idx);
-        });
+        bool median = depth + 1 + levels_for(n, leaf_size) >= MIRT_BVH_STACK; /* no room left for an unbalanced split */
+        if (!median) { /* binned SAH over the three axes */
+            const int NB = 16;
+            double best_cost = 1e300;
+            int best_ax = -1, best_bin = 0;
+            for (int a = 0; a < 3; ++a) {
+                const double ext = mx[a] - mn[a];
+                if (!(ext > 0)) continue;
+                BvhBox bins[NB];
+                size_t cnt[NB] = {0};
+                for (size_t i = lo; i < hi; ++i) {
+                    int k = (int)((b[i].M[a] - mn[a]) / ext * NB);
+                    k = k < 0 ? 0 : (k >= NB ? NB - 1 : k);
+                    bins[k].add(b[i]);
+                    ++cnt[k];
+                }
+                BvhBox left[NB], right[NB];
+                size_t cl[NB], cr[NB];
+                BvhBox acc;
+                size_t c = 0;
+                for (int k = 0; k < NB; ++k) { if (cnt[k]) acc.add(bins[k]); c += cnt[k]; left[k] = acc; cl[k] = c; }
+                acc = BvhBox();
+                c = 0;
+                for (int k = NB - 1; k >= 0; --k) { if (cnt[k]) acc.add(bins[k]); c += cnt[k]; right[k] = acc; cr[k] = c; }
+                for (int k = 0; k + 1 < NB; ++k) {
+                    if (cl[k] == 0 || cr[k + 1] == 0) continue;
+                    double cost = left[k].area() * (double)cl[k] + right[k + 1].area() * (double)cr[k + 1];
+                    if (cost < best_cost) { best_cost = cost; best_ax = a; best_bin = k; }
+                }
+            }
+            if (best_ax < 0) {
+                median = true; /* all centres coincide */
+            } else {
+                const double ext = mx[best_ax] - mn[best_ax], m0 = mn[best_ax];
+                const int a = best_ax, kb = best_bin;
+                auto it = std::partition(b.begin() + lo, b.begin() + hi, [=](const BallRec& x) {
+                    int k = (int)((x.M[a] - m0) / ext * 16);
+                    k = k < 0 ? 0 : (k >= 16 ? 15 : k);
+                    return k <= kb;
+                });
+                mid = (size_t)(it - b.begin());
+                if (mid == lo || mid == hi) median = true;
+            }
+        }
+        if (median) {
+            mid = lo + n / 2;
+            std::nth_element(b.begin() + lo, b.begin() + mid, b.begin() + hi, [ax](const BallRec& x, const BallRec& y) {
+                return x.M[ax] < y.M[ax] || (x.M[ax] == y.M[ax] && x.idx < y.idx);
+            });
+        }
         uint32_t me = (uint32_t)nodes.size();
         nodes.push_back(BvhNode{});
         uint32_t l = build(lo, mid, depth + 1), r = build(mid, hi, depth + 1);
+        float l0[3], h0[3], l1[3], h1[3];
+        child_box(lo, mid, l0, h0);
+        child_box(mid, hi, l1, h1);
         BvhNode nd;
-        child_record(lo, mid, l, nd.m[0], nd.p[0]);
-        child_record(mid, hi, r, nd.m[1], nd.p[1]);
+        nd.q0 = float4{l0[0], l0[1], l0[2], h0[0]};
+        nd.q1 = float4{h0[1], h0[2], l1[0], l1[1]};
+        nd.q2 = float4{l1[2], h1[0], h1[1], h1[2]};
+        nd.q3 = float4{u2f(l), u2f(r), 0.f, 0.f};
         nodes[me] = nd;
         return me;
     }
@@ -158,12 +204,10 @@ static int build_bvh(mirt_scene* s, std::vector<BallRec>& balls, const std::vect
     s->bvh_root = MIRT_BVH_NONE;
     if (balls.empty()) { s->bvh_ok = true; return MIRT_OK; } /* empty scene: every ray misses */
     if (balls.size() >= (1u << 27)) return MIRT_OK;          /* leaf refs hold 28 bits of record index: no tree, flag rejected */
-    uint32_t leaf = 4;
-    while (leaf < 8 && ((balls.size() + leaf - 1) / leaf) > (1ull << MIRT_BVH_STACK)) ++leaf;
-    BvhBuild bb{balls, {}, {}, {}, S, leaf};
+    BvhBuild bb{balls, {}, {}, {}, S, 4};
     uint32_t root = bb.build(0, balls.size(), 0);
-    if (bb.depth_max > MIRT_BVH_STACK) return MIRT_OK; /* deeper than the traversal stack: MIRT_FLAG_BVH is refused for this scene */
-    bb.leafS.push_back(float4{0.f, 0.f, 0.f, INFINITY}); /* leaf reads fetch whole pairs */
+    if (bb.depth_max > MIRT_BVH_STACK) return MIRT_OK; /* cannot happen below 2^27 records (median fallback), kept as a guard */
+    for (int k = 0; k < 8; ++k) bb.leafS.push_back(float4{0.f, 0.f, 0.f, INFINITY}); /* leaf reads fetch four records at a time */
     int rc;
     if ((rc = upload(s, bb.nodes, &s->bvh)) || (rc = upload(s, bb.leafS, &s->bvh_S)) || (rc = upload(s, bb.leafIdx, &s->bvh_idx))) return rc;
     s->bvh_root = root;
@@ -545,6 +589,10 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
                 fprintf(stderr, "[mirt phase timing] wave-cycles:");
                 for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h.phase_cycles[i] / (double)(tot ? tot : 1));
                 fprintf(stderr, "  (total %.3g cycles, %.0f per wave-iteration)\n", (double)tot, (double)tot / (double)(h.wave_iters ? h.wave_iters : 1));
+                if (h.bvh_wave_steps)
+                    fprintf(stderr, "[mirt phase timing] tree: %.1f node steps per segment, %.1f wave-level steps and %.2f leaf rounds per wave-iteration, %.2f leaves per segment\n",
+                            (double)h.bvh_lane_steps / (double)(h.segments ? h.segments : 1), (double)h.bvh_wave_steps / (double)(h.wave_iters ? h.wave_iters : 1),
+                            (double)h.bvh_leaf_rounds / (double)(h.wave_iters ? h.wave_iters : 1), (double)h.bvh_lane_leaves / (double)(h.segments ? h.segments : 1));
                 double span = (double)(h.end_max - ~h.inv_start_max) * 1e-5; /* 100 MHz ticks -> ms */
                 double life = (double)h.life_sum / (double)(h.n_waves ? h.n_waves : 1) * 1e-5;
                 fprintf(stderr, "[mirt phase timing] %llu waves, first start -> last end %.3f ms, mean wave lifetime %.3f ms (%.1f%% of the span)\n",

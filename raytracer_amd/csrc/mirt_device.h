@@ -83,17 +83,18 @@ template <class R> struct DevMaterial {
     R reflectance, fuzz, ior;
     V3<R> albedo;
 };
-/* Node of the bounding-ball tree (MIRT_FLAG_BVH): the test data of BOTH children, one 64-byte fetch per step.
- *   m  = (M.x, M.y, M.z, w)   centre of the child's ball, w = |M|^2 - R^2 - 160 eps (|M|^2 + R^2)
- *   p  = (c, R, ref, -)       c = 2 s R, R = rho + s (|M| + rho) with s = MIRT_BVH_S: see trace_bvh
- *   ref (bit pattern in p.z): bit 31 set = leaf, bits 3..30 first record, bits 0..2 count - 1; clear = node index;
- *                             0xFFFFFFFF = no child */
+/* Node of the bounding-volume tree (MIRT_FLAG_BVH): the boxes of BOTH children, one 64-byte fetch per step.
+ *   q0 = (lo0.x, lo0.y, lo0.z, hi0.x)  q1 = (hi0.y, hi0.z, lo1.x, lo1.y)  q2 = (lo1.z, hi1.x, hi1.y, hi1.z)
+ *   q3 = (ref0, ref1, -, -) as bit patterns
+ * A child's box is the box of its leaves' bounding balls, widened on the host by s * max_i(|M_i| + rho_i) (s = MIRT_BVH_S);
+ * the ray adds s |O| at run time (trace_bvh has the derivation).
+ * ref: bit 31 set = leaf, bits 3..30 first record, bits 0..2 count - 1; clear = node index; 0xFFFFFFFF = none */
 struct BvhNode {
-    float4 m[2], p[2];
+    float4 q0, q1, q2, q3;
 };
 #define MIRT_BVH_S 4.0e-3f
 #define MIRT_BVH_NONE 0xFFFFFFFFu
-#define MIRT_BVH_STACK 16
+#define MIRT_BVH_STACK 32
 
 template <class R> struct DevScene {
     /* spheres, statics first: [0, n_static) static, [n_static, n) moving; both counts are padded to a
@@ -113,7 +114,7 @@ template <class R> struct DevScene {
     unsigned long long* dbg;         /* diagnostic builds: counter of broad-phase misses (must stay 0) */
     uint32_t n, n_static;
     uint32_t n_materials;
-    /* bounding-ball tree (f32 only): nodes, the bounding records in leaf order, leaf slot -> sorted sphere index */
+    /* bounding-volume tree (f32 only): nodes, the bounding records in leaf order, leaf slot -> sorted sphere index */
     const BvhNode* bvh;
     const float4* bvh_S;
     const uint32_t* bvh_idx;

@@ -421,78 +421,81 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
 #undef MIRT_CONS_PUSH
 }
 
-/* ---- f32, MIRT_FLAG_BVH: closest hit through the bounding-ball tree -----------------------------------
- * Per-lane stack traversal (stack in LDS, one entry per level) of the tree built by mirt_scene_create; the leaves
- * hold the same (M, w) bounding records as the brute-force broad phase and are tested with the same expression, the
- * survivors go through the same exact narrow_test: the result is the brute-force result, sphere for sphere.
+/* ---- f32, MIRT_FLAG_BVH: closest hit through the bounding-volume tree --------------------------------
+ * Per-lane stack traversal (stack in LDS) of the tree built by mirt_scene_create; the leaves hold the same (M, w)
+ * bounding records as the brute-force broad phase and are tested with the same expression, the survivors go through
+ * the same exact narrow_test: the result is the brute-force result, sphere for sphere.
  *
  * Why a node may be skipped.  The leaf test is conservative for the exact test (trace_cons), and it passes only if the
  * real line comes within sqrt(rho_i^2 + G_i) <= rho_i + sqrt(G_i) of M_i, where G_i <= 240 eps (|M_i| + rho_i + |O|)^2
  * collects its margins and evaluation error, i.e. sqrt(G_i) <= s (|M_i| + rho_i + |O|) with s = MIRT_BVH_S = 4e-3
- * >= 15.5 sqrt(eps).  A node ball (M_n, rho_n) encloses its leaf balls, so |M_i| + rho_i <= |M_n| + rho_n and the line
- * comes within  rho_n + s (|M_n| + rho_n) + s |O| = R_n + s |O|  of M_n.  Squared and expanded like the leaf test:
- *     q_n = h^2 + 2 O.M_n - |O|^2 (1 - s^2) - (|M_n|^2 - R_n^2) + 2 s R_n |O|  >=  0
- * with the same 160 eps margins for its own evaluation (folded into w_n and the shrink of |O|^2): 10 VALU per child.
- * The exact root t of any sphere under the node puts the point O + t D within R_n + s |O| of M_n as well (its error is
- * <= 3.3 sqrt(eps) max(|C - O|, |C|)), so with u = R_n + s |O| and tau = t |D|:
- *     h + u < 0          the whole ball is behind the origin    -> no root > tmin > 0 in it
- *     h - u > tau_best   the whole ball is beyond the best hit  -> no root < best.t in it (ties are not beyond) */
-#define MIRT_NODE_SHRINK 0.99997f /* <= 1 - 160 eps - s^2 (1 + 1e-3) */
+ * >= 15.5 sqrt(eps).  The exact root t of the sphere puts the point O + t D within the same distance of M_i (its error
+ * is <= 3.3 sqrt(eps) max(|C - O|, |C|)).  So line and hit point lie inside the box of ball i widened by
+ * s (|M_i| + rho_i) + s |O| per axis; a node's box is the union over its leaves, widened on the host by
+ * s max_i(|M_i| + rho_i), and the ray contributes delta = s |O| by shifting its origin: the slab parameters are
+ * (lo - (O + delta)) / D and (hi - (O - delta)) / D.  They carry a relative rounding error of 2 eps, hence the
+ * factors (1 +- 1e-5) in the three tests
+ *     tnear <= tfar    the line meets the widened box
+ *     tfar  >= tmin    ... not wholly behind the origin
+ *     tnear <= best.t  ... not wholly beyond the best hit (ties are not beyond) */
 __device__ inline void trace_bvh(const DevScene<float>& sc, uint32_t (*stk)[MIRT_WAVE], uint32_t lane, bool active, const RayT<float>& ray, float tmin,
                                  Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
     best.t = INFINITY;
     best.idx = 0xFFFFFFFFu;
     const V3<float> O = ray.o;
     const float a_true = ray_a(ray.d);
-    const float len = sqrtf(a_true);
-    const float inv = 1.0f / len;
+    const float inv = 1.0f / sqrtf(a_true);
     const V3<float> Dn = {ray.d.x * inv, ray.d.y * inv, ray.d.z * inv};
     const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
     const float o2 = __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x));
-    const float nk2 = -(o2 * MIRT_RAY_SHRINK), nk2n = -(o2 * MIRT_NODE_SHRINK);
-    const float o1 = sqrtf(o2) * 1.000001f;
+    const float nk2 = -(o2 * MIRT_RAY_SHRINK);
     const V3<float> O2 = {O.x * 2.0f, O.y * 2.0f, O.z * 2.0f};
-    const float len_up = len * 1.00001f;
-    float tau_best = INFINITY;
+    /* slab constants: the per-ray widening delta = s |O| (rounded up), 1/D with |1/D| capped (D = 0 -> 1e30: a
+     * parallel ray gets +-huge parameters of the right sign instead of inf - inf) */
+    const float delta = sqrtf(o2) * (MIRT_BVH_S * 1.0001f) + 1e-30f;
+    const V3<float> Op = {O.x + delta, O.y + delta, O.z + delta}, Om = {O.x - delta, O.y - delta, O.z - delta};
+    auto cap_inv = [](float d) {
+        const float r = 1.0f / d;
+        return fabsf(r) <= 1e30f ? r : copysignf(1e30f, d); /* d = +-0 or denormal */
+    };
+    const V3<float> iD = {cap_inv(ray.d.x), cap_inv(ray.d.y), cap_inv(ray.d.z)};
+    const float tmin_dn = tmin * 0.99999f;
+    float best_up = INFINITY;
     uint32_t cur = active ? sc.bvh_root : MIRT_BVH_NONE, sp = 0;
+    /* "while-while": all lanes first walk inner nodes until each holds a leaf (or nothing), then the leaves are
+     * processed together */
     while (__ballot(cur != MIRT_BVH_NONE) != 0ull) {
-        if (cur != MIRT_BVH_NONE) {
-            if (cur & 0x80000000u) { /* leaf: the conservative record test, then the exact test */
-                const uint32_t first = (cur >> 3) & 0x0FFFFFFFu, cnt = (cur & 7u) + 1u;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    const float4 m = sc.bvh_S[first + k];
-                    const float h = __builtin_fmaf(Dn.z, m.z, __builtin_fmaf(Dn.y, m.y, __builtin_fmaf(Dn.x, m.x, -k1)));
-                    const float q = __builtin_fmaf(h, h, __builtin_fmaf(O2.z, m.z, __builtin_fmaf(O2.y, m.y, __builtin_fmaf(O2.x, m.x, nk2 - m.w))));
-                    if (q >= 0.0f) {
-                        narrow_test(sc, GeomGlobal<float>{sc}, sc.bvh_idx[first + k], ray, a_true, tmin, best);
-                        ++narrow_count;
-                    }
-                }
-                tau_best = best.t * len_up;
-                cur = MIRT_BVH_NONE;
-                if (sp > 0) cur = stk[--sp][lane];
-            } else {
+        while (__ballot(cur != MIRT_BVH_NONE && !(cur & 0x80000000u)) != 0ull) {
+#ifdef MIRT_PHASE_TIMING
+            if (lane == 0) atomicAdd((unsigned long long*)sc.dbg + 6, 1ull);
+            if (cur != MIRT_BVH_NONE && !(cur & 0x80000000u)) atomicAdd((unsigned long long*)sc.dbg + 5, 1ull);
+#endif
+            if (cur != MIRT_BVH_NONE && !(cur & 0x80000000u)) {
                 const BvhNode& nd = sc.bvh[cur];
-                float hh[2];
-                bool pass[2];
-                uint32_t ref[2];
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const float4 m = nd.m[c], p = nd.p[c];
-                    ref[c] = __float_as_uint(p.z);
-                    const float h = __builtin_fmaf(Dn.z, m.z, __builtin_fmaf(Dn.y, m.y, __builtin_fmaf(Dn.x, m.x, -k1)));
-                    const float e = __builtin_fmaf(O2.z, m.z, __builtin_fmaf(O2.y, m.y, __builtin_fmaf(O2.x, m.x, nk2n - m.w)));
-                    const float q = __builtin_fmaf(h, h, __builtin_fmaf(p.x, o1, e));
-                    const float u = __builtin_fmaf(MIRT_BVH_S, o1, p.y) * 1.001f;
-                    hh[c] = h;
-                    pass[c] = q >= 0.0f && h + u >= 0.0f && h - u <= tau_best;
-                }
-                const bool swap = hh[1] < hh[0]; /* nearer centre first */
-                const uint32_t r_near = swap ? ref[1] : ref[0], r_far = swap ? ref[0] : ref[1];
-                const bool p_near = swap ? pass[1] : pass[0], p_far = swap ? pass[0] : pass[1];
+                const float4 q0 = nd.q0, q1 = nd.q1, q2 = nd.q2, q3 = nd.q3;
+                /* a parameter pair per axis and child; which of the two is the entry depends on the sign of D */
+                auto slab = [&](float lx, float ly, float lz, float hx, float hy, float hz, float& tn, float& tf) {
+                    const float ax = (lx - Op.x) * iD.x, bx = (hx - Om.x) * iD.x;
+                    const float ay = (ly - Op.y) * iD.y, by = (hy - Om.y) * iD.y;
+                    const float az = (lz - Op.z) * iD.z, bz = (hz - Om.z) * iD.z;
+                    tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+                    tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+                };
+                float tn0, tf0, tn1, tf1;
+                slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0, tf0);
+                slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1, tf1);
+                /* slack on the far side only matters where it is positive; tnear is compared after shrinking towards 0 */
+                const float tf0u = tf0 * 1.00001f, tf1u = tf1 * 1.00001f;
+                const float tn0d = tn0 > 0.0f ? tn0 * 0.99999f : tn0, tn1d = tn1 > 0.0f ? tn1 * 0.99999f : tn1;
+                const uint32_t ref0 = __float_as_uint(q3.x), ref1 = __float_as_uint(q3.y);
+                const bool p0 = tn0d <= tf0u && tf0u >= tmin_dn && tn0d <= best_up;
+                const bool p1 = tn1d <= tf1u && tf1u >= tmin_dn && tn1d <= best_up;
+                const bool swap = tn1 < tn0; /* nearer entry first */
+                const uint32_t r_near = swap ? ref1 : ref0, r_far = swap ? ref0 : ref1;
+                const bool p_near = swap ? p1 : p0, p_far = swap ? p0 : p1;
                 if (p_near) {
                     cur = r_near;
-                    if (p_far) stk[sp++][lane] = r_far; /* depth <= MIRT_BVH_STACK, checked at build time */
+                    if (p_far) stk[sp++][lane] = r_far; /* depth <= MIRT_BVH_STACK by construction */
                 } else if (p_far) {
                     cur = r_far;
                 } else {
@@ -500,6 +503,32 @@ __device__ inline void trace_bvh(const DevScene<float>& sc, uint32_t (*stk)[MIRT
                     if (sp > 0) cur = stk[--sp][lane];
                 }
             }
+        }
+#ifdef MIRT_PHASE_TIMING
+        if (lane == 0) atomicAdd((unsigned long long*)sc.dbg + 7, 1ull);
+        if (cur != MIRT_BVH_NONE) atomicAdd((unsigned long long*)sc.dbg + 8, 1ull);
+#endif
+        if (cur != MIRT_BVH_NONE) { /* a leaf: the conservative record tests (fetched at once), then the exact tests */
+            const uint32_t first = (cur >> 3) & 0x0FFFFFFFu, cnt = (cur & 7u) + 1u;
+            float4 m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = sc.bvh_S[first + k]; /* leaves hold <= 4 records; the array is padded */
+            uint32_t msk = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float h = __builtin_fmaf(Dn.z, m[k].z, __builtin_fmaf(Dn.y, m[k].y, __builtin_fmaf(Dn.x, m[k].x, -k1)));
+                const float q = __builtin_fmaf(h, h, __builtin_fmaf(O2.z, m[k].z, __builtin_fmaf(O2.y, m[k].y, __builtin_fmaf(O2.x, m[k].x, nk2 - m[k].w))));
+                if (q >= 0.0f && (uint32_t)k < cnt) msk |= 1u << k;
+            }
+            while (msk) {
+                const uint32_t k = (uint32_t)__ffs((int)msk) - 1u;
+                msk &= msk - 1u;
+                narrow_test(sc, GeomGlobal<float>{sc}, sc.bvh_idx[first + k], ray, a_true, tmin, best);
+                ++narrow_count;
+            }
+            best_up = best.t * 1.00001f;
+            cur = MIRT_BVH_NONE;
+            if (sp > 0) cur = stk[--sp][lane];
         }
     }
     pt.stamp(PH_BROAD);
@@ -714,6 +743,7 @@ struct DevStats { /* device-side counters, one atomic per wave at kernel end */
     unsigned long long end_max;         /* latest wave end */
     unsigned long long life_sum;        /* sum over waves of (end - start) */
     unsigned long long n_waves;
+    unsigned long long bvh_lane_steps, bvh_wave_steps, bvh_leaf_rounds, bvh_lane_leaves; /* MIRT_PHASE_TIMING + MIRT_FLAG_BVH */
 };
 
 template <class R> __device__ inline R wave_sum_u(R v) {
