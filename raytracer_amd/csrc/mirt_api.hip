@@ -49,7 +49,7 @@ struct mirt_scene {
     BvhNode* bvh = nullptr; /* bounding-ball tree (MIRT_FLAG_BVH) */
     float4* bvh_S = nullptr;
     uint32_t* bvh_idx = nullptr;
-    uint32_t bvh_root = MIRT_BVH_NONE;
+    uint32_t bvh_root = MIRT_BVH_NONE, bvh_n_nodes = 0, bvh_n_recs = 0, bvh_depth = 0;
     bool bvh_ok = false;
     DevImage* imgs = nullptr;
     DevStats* stats = nullptr; /* one per scene: calls on one scene handle are not re-entrant */
@@ -102,6 +102,7 @@ struct BvhBuild {
     std::vector<uint32_t> leafIdx;
     const std::vector<float4>& S;
     uint32_t leaf_size;
+    uint32_t depth_limit; /* stack entries the traversal has */
     uint32_t depth_max = 0;
 
     static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -134,7 +135,7 @@ struct BvhBuild {
         size_t mid = lo + n / 2;
         int ax = 0;
         for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[ax] - mn[ax]) ax = a;
-        bool median = depth + 1 + levels_for(n, leaf_size) >= MIRT_BVH_STACK; /* no room left for an unbalanced split */
+        bool median = depth + 1 + levels_for(n, leaf_size) >= depth_limit; /* no room left for an unbalanced split */
         if (!median) { /* binned SAH over the three axes */
             const int NB = 16;
             double best_cost = 1e300;
@@ -204,13 +205,18 @@ static int build_bvh(mirt_scene* s, std::vector<BallRec>& balls, const std::vect
     s->bvh_root = MIRT_BVH_NONE;
     if (balls.empty()) { s->bvh_ok = true; return MIRT_OK; } /* empty scene: every ray misses */
     if (balls.size() >= (1u << 27)) return MIRT_OK;          /* leaf refs hold 28 bits of record index: no tree, flag rejected */
-    BvhBuild bb{balls, {}, {}, {}, S, 4};
+    /* scenes that fit the LDS copy (render_kernel_f32_bvh_lds) get a tree for its shorter stack */
+    const bool small = balls.size() <= MIRT_LDS_RECORDS;
+    BvhBuild bb{balls, {}, {}, {}, S, 4, small ? (uint32_t)MIRT_BVH_LDS_STACK : (uint32_t)MIRT_BVH_STACK};
     uint32_t root = bb.build(0, balls.size(), 0);
     if (bb.depth_max > MIRT_BVH_STACK) return MIRT_OK; /* cannot happen below 2^27 records (median fallback), kept as a guard */
     for (int k = 0; k < 8; ++k) bb.leafS.push_back(float4{0.f, 0.f, 0.f, INFINITY}); /* leaf reads fetch four records at a time */
     int rc;
     if ((rc = upload(s, bb.nodes, &s->bvh)) || (rc = upload(s, bb.leafS, &s->bvh_S)) || (rc = upload(s, bb.leafIdx, &s->bvh_idx))) return rc;
     s->bvh_root = root;
+    s->bvh_n_nodes = (uint32_t)bb.nodes.size();
+    s->bvh_n_recs = (uint32_t)bb.leafIdx.size();
+    s->bvh_depth = bb.depth_max;
     s->bvh_ok = true;
     return MIRT_OK;
 }
@@ -266,6 +272,7 @@ template <class R> static DevScene<R> dev_scene(const mirt_scene* s, const Scene
     d.S = sizeof(R) == 4 ? s->S : nullptr;
     d.n_materials = s->n_materials;
     d.bvh = s->bvh; d.bvh_S = s->bvh_S; d.bvh_idx = s->bvh_idx; d.bvh_root = s->bvh_root;
+    d.bvh_n_nodes = s->bvh_n_nodes; d.bvh_n_recs = s->bvh_n_recs; d.bvh_depth = s->bvh_depth;
     d.dbg = s->stats ? &s->stats->broad_misses : nullptr;
     return d;
 }
@@ -339,22 +346,27 @@ static void choose_chunks(uint64_t n_pixels, uint32_t nsamples, size_t real_byte
 }
 
 /* the two render kernels behind one name */
-static const void* render_fn(double, bool) { return (const void*)render_kernel_f64<2>; }
-static const void* render_fn(float, bool bvh) { return bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
-static void launch_render_kernel(uint32_t grid, uint32_t block, bool, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam,
+static const void* render_fn(double, int) { return (const void*)render_kernel_f64<2>; }
+static const void* render_fn(float, int bvh) { return bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
+static void launch_render_kernel(uint32_t grid, uint32_t block, int, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam,
                                  const DevPart& part, const RenderParams& rp, double* partial, DevStats* stats) {
     hipLaunchKernelGGL(render_kernel_f64<2>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
 }
-static void launch_render_kernel(uint32_t grid, uint32_t block, bool bvh, hipStream_t st, const DevScene<float>& sc, const DevCamera<float>& cam,
+static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<float>& sc, const DevCamera<float>& cam,
                                  const DevPart& part, const RenderParams& rp, float* partial, DevStats* stats) {
-    if (bvh) hipLaunchKernelGGL(render_kernel_f32_bvh, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    if (bvh == 2) hipLaunchKernelGGL(render_kernel_f32_bvh_lds, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    else if (bvh) hipLaunchKernelGGL(render_kernel_f32_bvh, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else hipLaunchKernelGGL(render_kernel_f32, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
 }
 
 template <class R>
 static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mirt_camera* cam, const DevPart& part, uint64_t seed, void* d_lin,
-                         uint8_t* d_rgb8, hipStream_t st, bool bvh) {
-    const uint32_t block = (sizeof(R) == 4 && !bvh) ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;
+                         uint8_t* d_rgb8, hipStream_t st, bool use_bvh) {
+    /* tree traversal: 0 = no, 1 = tree in HBM/L2, 2 = tree, records and spheres resident in LDS */
+    const int bvh = !use_bvh ? 0
+                    : (s->bvh_n_nodes <= MIRT_BVH_LDS_NODES && s->bvh_n_recs <= MIRT_LDS_RECORDS && s->n <= MIRT_LDS_RECORDS &&
+                       s->bvh_depth <= MIRT_BVH_LDS_STACK && s->n_materials <= 0x10000u && s->bvh_root != MIRT_BVH_NONE) ? 2 : 1;
+    const uint32_t block = (sizeof(R) == 4 && bvh != 1) ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;
     uint64_t n_pixels = (uint64_t)cam->img_width * part.local_rows;
     if (n_pixels == 0) return MIRT_OK;
     RenderParams rp;

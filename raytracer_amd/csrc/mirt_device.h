@@ -118,7 +118,8 @@ template <class R> struct DevScene {
     const BvhNode* bvh;
     const float4* bvh_S;
     const uint32_t* bvh_idx;
-    uint32_t bvh_root; /* a ref like BvhNode::p.z */
+    uint32_t bvh_root; /* a ref like BvhNode::q3.x */
+    uint32_t bvh_n_nodes, bvh_n_recs, bvh_depth;
 };
 template <class R> struct DevCamera { /* struct Camera, camera/camera.rs:107-120, rounded once to Real */
     V3<R> lookfrom, du, dv, ul, px00, disk_u, disk_v;

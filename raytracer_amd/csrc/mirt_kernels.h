@@ -438,8 +438,59 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
  *     tnear <= tfar    the line meets the widened box
  *     tfar  >= tmin    ... not wholly behind the origin
  *     tnear <= best.t  ... not wholly beyond the best hit (ties are not beyond) */
-__device__ inline void trace_bvh(const DevScene<float>& sc, uint32_t (*stk)[MIRT_WAVE], uint32_t lane, bool active, const RayT<float>& ray, float tmin,
-                                 Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+/* where the tree lives: HBM/L2, or (scenes of <= MIRT_LDS_RECORDS spheres) a copy in the block's LDS */
+struct BvhGlobalStore {
+    const DevScene<float>& sc;
+    typedef GeomGlobal<float> Geom;
+    __device__ inline void node(uint32_t i, float4& q0, float4& q1, float4& q2, float4& q3) const {
+        const BvhNode& nd = sc.bvh[i];
+        q0 = nd.q0; q1 = nd.q1; q2 = nd.q2; q3 = nd.q3;
+    }
+    __device__ inline float4 rec(uint32_t i) const { return sc.bvh_S[i]; }
+    __device__ inline uint32_t idx(uint32_t i) const { return sc.bvh_idx[i]; }
+    __device__ inline Geom geom() const { return Geom{sc}; }
+};
+#define MIRT_BVH_LDS_NODES 256
+#define MIRT_BVH_LDS_STACK 16
+struct BvhLds { /* 133 KB: one block of 16 waves per CU */
+    BvhNode nodes[MIRT_BVH_LDS_NODES];
+    float4 S[MIRT_LDS_RECORDS + 8]; /* leaf order */
+    float4 A[MIRT_LDS_RECORDS], B[MIRT_LDS_RECORDS]; /* sorted-sphere order, as in HBM */
+    uint16_t mat[MIRT_LDS_RECORDS], idx[MIRT_LDS_RECORDS];
+    uint32_t stk[MIRT_F32_WAVES][MIRT_BVH_LDS_STACK][MIRT_WAVE];
+    __device__ inline void fill(const DevScene<float>& sc) { /* the host launches this kernel only if everything fits */
+        for (uint32_t i = threadIdx.x; i < sc.bvh_n_nodes; i += blockDim.x) nodes[i] = sc.bvh[i];
+        for (uint32_t i = threadIdx.x; i < sc.bvh_n_recs + 8; i += blockDim.x) S[i] = sc.bvh_S[i];
+        for (uint32_t i = threadIdx.x; i < sc.bvh_n_recs; i += blockDim.x) idx[i] = (uint16_t)sc.bvh_idx[i];
+        for (uint32_t i = threadIdx.x; i < sc.n; i += blockDim.x) {
+            A[i] = sc.A[i];
+            B[i] = sc.B[i];
+            mat[i] = (uint16_t)sc.material[i];
+        }
+        __syncthreads();
+    }
+};
+struct GeomBvhLds {
+    const BvhLds& L;
+    __device__ inline float4 a(uint32_t i) const { return L.A[i]; }
+    __device__ inline float4 b(uint32_t i) const { return L.B[i]; }
+    __device__ inline uint32_t material(uint32_t i) const { return L.mat[i]; }
+};
+struct BvhLdsStore {
+    const BvhLds& L;
+    typedef GeomBvhLds Geom;
+    __device__ inline void node(uint32_t i, float4& q0, float4& q1, float4& q2, float4& q3) const {
+        const BvhNode& nd = L.nodes[i];
+        q0 = nd.q0; q1 = nd.q1; q2 = nd.q2; q3 = nd.q3;
+    }
+    __device__ inline float4 rec(uint32_t i) const { return L.S[i]; }
+    __device__ inline uint32_t idx(uint32_t i) const { return L.idx[i]; }
+    __device__ inline Geom geom() const { return Geom{L}; }
+};
+
+template <class Store>
+__device__ inline void trace_bvh(const DevScene<float>& sc, const Store& store, uint32_t (*stk)[MIRT_WAVE], uint32_t lane, bool active, const RayT<float>& ray,
+                                 float tmin, Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
     best.t = INFINITY;
     best.idx = 0xFFFFFFFFu;
     const V3<float> O = ray.o;
@@ -471,8 +522,8 @@ __device__ inline void trace_bvh(const DevScene<float>& sc, uint32_t (*stk)[MIRT
             if (cur != MIRT_BVH_NONE && !(cur & 0x80000000u)) atomicAdd((unsigned long long*)sc.dbg + 5, 1ull);
 #endif
             if (cur != MIRT_BVH_NONE && !(cur & 0x80000000u)) {
-                const BvhNode& nd = sc.bvh[cur];
-                const float4 q0 = nd.q0, q1 = nd.q1, q2 = nd.q2, q3 = nd.q3;
+                float4 q0, q1, q2, q3;
+                store.node(cur, q0, q1, q2, q3);
                 /* a parameter pair per axis and child; which of the two is the entry depends on the sign of D */
                 auto slab = [&](float lx, float ly, float lz, float hx, float hy, float hz, float& tn, float& tf) {
                     const float ax = (lx - Op.x) * iD.x, bx = (hx - Om.x) * iD.x;
@@ -512,7 +563,7 @@ __device__ inline void trace_bvh(const DevScene<float>& sc, uint32_t (*stk)[MIRT
             const uint32_t first = (cur >> 3) & 0x0FFFFFFFu, cnt = (cur & 7u) + 1u;
             float4 m[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) m[k] = sc.bvh_S[first + k]; /* leaves hold <= 4 records; the array is padded */
+            for (int k = 0; k < 4; ++k) m[k] = store.rec(first + k); /* leaves hold <= 4 records; the array is padded */
             uint32_t msk = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -523,7 +574,7 @@ __device__ inline void trace_bvh(const DevScene<float>& sc, uint32_t (*stk)[MIRT
             while (msk) {
                 const uint32_t k = (uint32_t)__ffs((int)msk) - 1u;
                 msk &= msk - 1u;
-                narrow_test(sc, GeomGlobal<float>{sc}, sc.bvh_idx[first + k], ray, a_true, tmin, best);
+                narrow_test(sc, store.geom(), store.idx(first + k), ray, a_true, tmin, best);
                 ++narrow_count;
             }
             best_up = best.t * 1.00001f;
@@ -578,15 +629,16 @@ template <bool RES> struct TracerF32 {
     __device__ inline uint32_t material(uint32_t idx) const { return RES ? (uint32_t)L.mat[idx] : sc.material[idx]; }
 };
 
-struct TracerF32Bvh {
+template <class Store> struct TracerF32Bvh {
     typedef float Real;
     const DevScene<float>& sc;
+    Store store;
     uint32_t (*stk)[MIRT_WAVE];
     __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
-        trace_bvh(sc, stk, lane, active, ray, tmin, best, nc, pt);
+        trace_bvh(sc, store, stk, lane, active, ray, tmin, best, nc, pt);
     }
-    __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const { return make_hit(sc, GeomGlobal<float>{sc}, c, ray); }
-    __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }
+    __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const { return make_hit(sc, store.geom(), c, ray); }
+    __device__ inline uint32_t material(uint32_t idx) const { return store.geom().material(idx); }
 };
 
 /* ---- textures: scene/texture.rs ----------------------------------------------------------------- */
@@ -801,7 +853,7 @@ __global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel_f32_bvh(DevSce
                                                                           float* __restrict__ out_t) {
     __shared__ uint32_t stk[MIRT_WAVES_PER_BLOCK][MIRT_BVH_STACK][MIRT_WAVE];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    TracerF32Bvh tr{sc, stk[w]};
+    TracerF32Bvh<BvhGlobalStore> tr{sc, BvhGlobalStore{sc}, stk[w]};
     primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_WAVES_PER_BLOCK + w, lane, out_id, out_t);
 }
 
@@ -985,7 +1037,16 @@ __global__ __launch_bounds__(MIRT_BLOCK) void render_kernel_f32_bvh(DevScene<flo
                                                                     float* __restrict__ partial, DevStats* __restrict__ stats) {
     __shared__ uint32_t stk[MIRT_WAVES_PER_BLOCK][MIRT_BVH_STACK][MIRT_WAVE];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    TracerF32Bvh tr{sc, stk[w]};
+    TracerF32Bvh<BvhGlobalStore> tr{sc, BvhGlobalStore{sc}, stk[w]};
+    render_body(tr, sc, cam, part, rp, partial, stats, lane);
+}
+/* the same for scenes whose tree, records and spheres fit the LDS: one block of 16 waves per CU, no HBM in the loop */
+__global__ __launch_bounds__(MIRT_F32_BLOCK) void render_kernel_f32_bvh_lds(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
+                                                                            float* __restrict__ partial, DevStats* __restrict__ stats) {
+    __shared__ BvhLds L;
+    L.fill(sc);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    TracerF32Bvh<BvhLdsStore> tr{sc, BvhLdsStore{L}, L.stk[w]};
     render_body(tr, sc, cam, part, rp, partial, stats, lane);
 }
 /* one block of 16 waves per CU: 4 waves per SIMD, <= 128 VGPRs */
