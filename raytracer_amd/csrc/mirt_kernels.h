@@ -517,7 +517,7 @@ __device__ inline void trace_bvh(const DevScene<float>& sc, const Store& store, 
      * processed together */
     while (__ballot(cur != MIRT_BVH_NONE) != 0ull) {
         while (__ballot(cur != MIRT_BVH_NONE && !(cur & 0x80000000u)) != 0ull) {
-#ifdef MIRT_PHASE_TIMING
+#ifdef MIRT_BVH_COUNTERS
             if (lane == 0) atomicAdd((unsigned long long*)sc.dbg + 6, 1ull);
             if (cur != MIRT_BVH_NONE && !(cur & 0x80000000u)) atomicAdd((unsigned long long*)sc.dbg + 5, 1ull);
 #endif
@@ -555,7 +555,7 @@ __device__ inline void trace_bvh(const DevScene<float>& sc, const Store& store, 
                 }
             }
         }
-#ifdef MIRT_PHASE_TIMING
+#ifdef MIRT_BVH_COUNTERS
         if (lane == 0) atomicAdd((unsigned long long*)sc.dbg + 7, 1ull);
         if (cur != MIRT_BVH_NONE) atomicAdd((unsigned long long*)sc.dbg + 8, 1ull);
 #endif
@@ -795,7 +795,7 @@ struct DevStats { /* device-side counters, one atomic per wave at kernel end */
     unsigned long long end_max;         /* latest wave end */
     unsigned long long life_sum;        /* sum over waves of (end - start) */
     unsigned long long n_waves;
-    unsigned long long bvh_lane_steps, bvh_wave_steps, bvh_leaf_rounds, bvh_lane_leaves; /* MIRT_PHASE_TIMING + MIRT_FLAG_BVH */
+    unsigned long long bvh_lane_steps, bvh_wave_steps, bvh_leaf_rounds, bvh_lane_leaves; /* -DMIRT_PHASE_TIMING -DMIRT_BVH_COUNTERS */
 };
 
 template <class R> __device__ inline R wave_sum_u(R v) {

@@ -1,0 +1,89 @@
+/*
+ * mirt_cli.cpp — command-line front end over the C++ host mirror: what the reference's main()
+ * (/root/reference/src/main.rs:29-134) does with one hard-coded scene and camera, for all five of its scenes.
+ *
+ *   mirt_cli render --scene mars|bouncing_balls|scene|scene2|blur_scene [--width 400] [--spp 100] [--depth 50]
+ *                   [--seed 1] [--layout-seed 1] [--precision 64|32] [--accel brute|bvh] [--textures DIR] [--out FILE]
+ *        PPM P3 on stdout (or FILE), like the reference.  --spp 0 = the no-anti-aliasing branch.
+ *   mirt_cli decode IN.jpg OUT.ppm      the image loader alone (binary PPM out)
+ */
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <map>
+
+#include "presets.hpp"
+
+using namespace raytracer;
+
+static int usage() {
+    std::cerr << "usage: mirt_cli render --scene NAME [--width W] [--spp N] [--depth D] [--seed S] [--layout-seed S] [--precision 64|32]\n"
+                 "                       [--accel brute|bvh] [--textures DIR] [--out FILE]\n"
+                 "       mirt_cli decode IN.jpg OUT.ppm\n";
+    return 2;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) return usage();
+    const std::string cmd = argv[1];
+    try {
+        if (cmd == "decode") {
+            if (argc != 4) return usage();
+            uint32_t w, h;
+            std::vector<uint8_t> rgb;
+            load_image_to_rgb(argv[2], w, h, rgb);
+            std::ofstream o(argv[3], std::ios::binary);
+            o << "P6\n" << w << " " << h << "\n255\n";
+            o.write((const char*)rgb.data(), (std::streamsize)rgb.size());
+            return o ? 0 : 1;
+        }
+        if (cmd != "render") return usage();
+        std::map<std::string, std::string> opt = {{"--scene", "mars"}, {"--width", "400"}, {"--spp", "100"}, {"--depth", "50"}, {"--seed", "1"},
+                                                  {"--layout-seed", "1"}, {"--precision", "64"}, {"--accel", "brute"},
+                                                  {"--textures", "./presets/textures"}, {"--out", ""}};
+        for (int i = 2; i < argc; i += 2) {
+            if (i + 1 >= argc || !opt.count(argv[i])) return usage();
+            opt[argv[i]] = argv[i + 1];
+        }
+        const uint32_t width = (uint32_t)std::atoi(opt["--width"].c_str()), spp = (uint32_t)std::atoi(opt["--spp"].c_str());
+        const uint32_t depth = (uint32_t)std::atoi(opt["--depth"].c_str());
+        const std::string name = opt["--scene"];
+        Scene scene;
+        Camera cam;
+        if (name == "mars") {
+            presets::mars_texture_scene(scene, opt["--textures"]);
+            cam = presets::default_camera(width, spp, depth);
+        } else if (name == "bouncing_balls") {
+            presets::bouncing_balls_scene(scene, opt["--textures"], std::strtoull(opt["--layout-seed"].c_str(), nullptr, 10));
+            cam = presets::default_camera(width, spp, depth, Point(13.0, 2.0, 3.0));
+        } else if (name == "scene") {
+            presets::scene(scene);
+            cam = presets::plain_camera(width, spp, depth);
+        } else if (name == "scene2") {
+            presets::scene2(scene);
+            cam = presets::plain_camera(width, spp, depth);
+        } else if (name == "blur_scene") {
+            presets::blur_scene(scene);
+            cam = presets::plain_camera(width, spp, depth);
+        } else {
+            std::cerr << "unknown scene " << name << "\n";
+            return 2;
+        }
+        scene.build_bvh();
+        cam.seed = std::strtoull(opt["--seed"].c_str(), nullptr, 10);
+        cam.precision = opt["--precision"] == "32" ? MIRT_F32 : MIRT_F64;
+        cam.use_bvh = opt["--accel"] == "bvh";
+        if (opt["--out"].empty()) {
+            cam.render(scene, std::cout);
+        } else {
+            std::ofstream o(opt["--out"], std::ios::binary);
+            cam.render(scene, o);
+        }
+        std::cerr << name << ": " << scene.len() << " objects, " << cam.pod.img_width << "x" << cam.pod.img_height << ", segments "
+                  << cam.last_stats.segments << ", kernel " << cam.last_stats.kernel_ms << " ms\n";
+    } catch (const std::exception& e) {
+        std::cerr << "error: " << e.what() << "\n";
+        return 1;
+    }
+    return 0;
+}

@@ -115,6 +115,48 @@ def bouncing_balls_scene(seed: int = 1) -> Scene:
     return scene
 
 
+def plain_camera(img_width=400, aa_samples_per_px: Optional[int] = 100, max_depth=50) -> Camera:
+    """The all-defaults camera (camera.rs:135-149) the three small scenes of main.rs:74-121 were written for."""
+    return Camera.build(None, None, None, img_width, 16.0 / 9.0, aa_samples_per_px, None, None, None, max_depth)
+
+
+def _small_scene_materials():
+    return (Lambertian.new((0.8, 0.8, 0.1), 1.0), Lambertian.new((0.7, 0.2, 0.8), 1.0), Dielectric.new(1.5),
+            Dielectric.new(1.0 / 1.5), Metal.new((0.8, 0.6, 0.2), 0.5))
+
+
+def scene2() -> Scene:
+    """main.rs:74-87 (built by main(), never rendered)."""
+    r = math.cos(math.pi / 4.0)
+    sc = Scene()
+    sc.add(Sphere.new_static(r, (-r, 0.0, -1.0), Lambertian.new((1.0, 1.0, 0.0), 1.0)))
+    sc.add(Sphere.new_static(r, (r, 0.0, -1.0), Lambertian.new((0.0, 1.0, 1.0), 1.0)))
+    sc.build_bvh()
+    return sc
+
+
+def scene() -> Scene:
+    """main.rs:95-107."""
+    g, c, l, b, r = _small_scene_materials()
+    sc = Scene()
+    for rad, ctr, m in ((100.0, (0.0, -100.5, -1.0), g), (0.5, (0.0, 0.0, -3.2), c), (0.5, (-1.0, 0.0, -2.5), l), (0.3, (-1.0, 0.0, -2.5), b),
+                        (0.4, (1.0, 0.0, -1.0), r), (0.4, (6.0, 0.0, -10.0), r), (0.5, (-3.0, 0.0, -1.6), c)):
+        sc.add(Sphere.new_static(rad, ctr, m))
+    sc.build_bvh()
+    return sc
+
+
+def blur_scene() -> Scene:
+    """main.rs:109-121."""
+    g, c, l, b, r = _small_scene_materials()
+    sc = Scene()
+    for rad, ctr, m in ((100.0, (0.0, -100.5, -1.0), g), (0.5, (0.0, 0.0, -1.2), c), (0.5, (-1.0, 0.0, -1.0), l), (0.3, (-1.0, 0.0, -1.0), b),
+                        (0.4, (1.0, 0.0, -1.0), r), (0.4, (6.0, 0.0, -10.0), r), (0.5, (-3.0, 0.0, -1.6), c)):
+        sc.add(Sphere.new_static(rad, ctr, m))
+    sc.build_bvh()
+    return sc
+
+
 def textured_scene() -> Scene:
     """C4: image + procedural textures from presets/textures: a mars sphere, an earth sphere, checker ground."""
     scene = Scene()

@@ -76,3 +76,121 @@ def test_cpp_example_ppm_equals_python_mirror(prec):
     cam.render(_example_scene(), out=buf)
     assert r.stdout == buf.getvalue()
     assert r.stdout.startswith(b"P3\n96 54\n255\n")
+
+
+# ---- image loader and preset front end (f4) ------------------------------------------------------------
+CLI = os.path.join(HOST, "mirt_cli")
+ASSETS = os.path.join(ROOT, "raytracer_amd", "assets")
+
+
+def _cli():
+    if not os.path.exists(CLI):
+        r = subprocess.run(["make", "-C", HOST], capture_output=True, text=True)
+        if r.returncode != 0:
+            pytest.skip("mirt_cli not built: " + r.stderr[-300:])
+    return CLI
+
+
+def _read_p6(path):
+    import numpy as np
+
+    d = open(path, "rb").read()
+    magic, dims, maxv, body = d.split(b"\n", 3)
+    w, h = map(int, dims.split())
+    assert magic == b"P6" and maxv == b"255"
+    return np.frombuffer(body, dtype=np.uint8).reshape(h, w, 3)
+
+
+def _synthetic_image(w, h):
+    import numpy as np
+
+    y, x = np.mgrid[0:h, 0:w]
+    rng = np.random.default_rng(3)
+    img = np.stack([127 + 120 * np.sin(x / 9.0) * np.cos(y / 13.0), (x * 255 / w), 255 - (y * 255 / h)], axis=-1)
+    img += rng.normal(0, 6, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("subsampling,w,h,tol_max,tol_mean", [(0, 200, 120, 4, 0.2), (0, 67, 45, 4, 0.2), (2, 160, 96, 64, 3.0), (-1, 64, 64, 1, 0.05)])
+def test_jpeg_decoder_against_libjpeg(tmp_path, subsampling, w, h, tol_max, tol_mean):
+    """Baseline decode of PIL-written files vs PIL's own (libjpeg) decode.  4:4:4 and grayscale: within the +-1 of the
+    IDCT times the colour matrix; 4:2:0: libjpeg interpolates chroma where this decoder replicates it (loose bound).
+    subsampling -1 = grayscale; odd sizes exercise the partial MCUs; one case uses restart markers."""
+    import numpy as np
+    from PIL import Image
+
+    img = _synthetic_image(w, h)
+    src = tmp_path / "t.jpg"
+    if subsampling < 0:
+        Image.fromarray(img[..., 0]).save(src, quality=92)
+    else:
+        Image.fromarray(img).save(src, quality=92, subsampling=subsampling, **({"restart_marker_rows": 1} if w == 67 else {}))
+    want = np.asarray(Image.open(src).convert("RGB")).astype(int)
+    out = tmp_path / "t.ppm"
+    subprocess.run([_cli(), "decode", str(src), str(out)], check=True, capture_output=True)
+    got = _read_p6(out).astype(int)
+    assert got.shape == want.shape
+    d = np.abs(got - want)
+    assert d.max() <= tol_max and d.mean() <= tol_mean, (d.max(), d.mean())
+
+
+def test_jpeg_decoder_rejects_progressive_and_garbage(tmp_path):
+    from PIL import Image
+
+    src = tmp_path / "p.jpg"
+    Image.fromarray(_synthetic_image(32, 32)).save(src, progressive=True)
+    r = subprocess.run([_cli(), "decode", str(src), str(tmp_path / "o.ppm")], capture_output=True, text=True)
+    assert r.returncode == 1 and "baseline" in r.stderr
+    bad = tmp_path / "bad.jpg"
+    bad.write_bytes(b"\xff\xd8\xff\xdb\x00\x02garbage")
+    r = subprocess.run([_cli(), "decode", str(bad), str(tmp_path / "o.ppm")], capture_output=True, text=True)
+    assert r.returncode == 1 and "error" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/presets/textures"), reason="the reference's textures are only in the build container")
+@pytest.mark.parametrize("stem", ["earthmap", "mars_1k_color"])
+def test_jpeg_decoder_on_the_reference_textures(tmp_path, stem):
+    """The files ImageTexture is fed with in main.rs:138-141,154-157, against the libjpeg decode shipped in assets/."""
+    import numpy as np
+
+    out = tmp_path / "o.ppm"
+    subprocess.run([_cli(), "decode", f"/root/reference/presets/textures/{stem}.jpg", str(out)], check=True, capture_output=True)
+    got = _read_p6(out).astype(int)
+    with np.load(os.path.join(ASSETS, "textures.npz")) as z:
+        want = z[stem].astype(int)
+    d = np.abs(got - want)
+    assert got.shape == (512, 1024, 3) and d.max() <= 4 and d.mean() < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,args", [("mars", ["--width", "80", "--spp", "2", "--depth", "8", "--precision", "64"]),
+                                       ("bouncing_balls", ["--width", "96", "--spp", "2", "--depth", "12", "--precision", "32"]),
+                                       ("bouncing_balls", ["--width", "96", "--spp", "0", "--depth", "12", "--precision", "32", "--accel", "bvh"]),
+                                       ("scene", ["--width", "64", "--spp", "3", "--depth", "10", "--precision", "64"]),
+                                       ("scene2", ["--width", "64", "--spp", "0", "--depth", "10", "--precision", "64"]),
+                                       ("blur_scene", ["--width", "64", "--spp", "3", "--depth", "10", "--precision", "32"])])
+def test_cli_presets_equal_python_presets(name, args):
+    """Both front ends must build the same scene (same seeded layout, same flattening) and camera: equal PPM bytes."""
+    from raytracer_amd import presets
+
+    if not os.path.exists(os.path.join(ASSETS, "earthmap.ppm")):
+        import __graft_entry__
+
+        __graft_entry__.export_textures()
+    r = subprocess.run([_cli(), "render", "--scene", name, "--seed", "5", "--layout-seed", "1", "--textures", ASSETS] + args, capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    kv = dict(zip(args[::2], args[1::2]))
+    w, spp, depth = int(kv["--width"]), int(kv["--spp"]), int(kv["--depth"])
+    sc, cam = {
+        "mars": lambda: (presets.mars_texture_scene(), presets.default_camera(w, spp, depth)),
+        "bouncing_balls": lambda: (presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(w, spp, depth)),
+        "scene": lambda: (presets.scene(), presets.plain_camera(w, spp, depth)),
+        "scene2": lambda: (presets.scene2(), presets.plain_camera(w, spp, depth)),
+        "blur_scene": lambda: (presets.blur_scene(), presets.plain_camera(w, spp, depth)),
+    }[name]()
+    cam.seed, cam.precision = 5, (abi.F64 if kv["--precision"] == "64" else abi.F32)
+    _, rgb8 = cam.render_arrays(sc, want_linear=False, accel="bvh" if kv.get("--accel") == "bvh" else None)
+    from raytracer_amd.api import ppm_body
+
+    want = f"P3\n{cam.width} {cam.height}\n255\n".encode() + ppm_body(rgb8)
+    assert r.stdout == want
