@@ -191,7 +191,9 @@ def main():
                 "peak": FP32_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
-                "traffic": None,
+                # HBM bytes per launch of this kernel, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE in separate passes
+                # (profiles/r01_v5_hbm_traffic.txt; not re-measured by this script).  Only quoted for the workload it was taken on.
+                "traffic": 8.3e8 if (args.workload == "balls1080p" and (W, cam.pod.samples_per_pixel, args.precision, args.accel, world) == (1920, 64, 32, "brute", 1)) else None,
                 "kernel": ("render_kernel_f32" if args.accel == "brute" else "render_kernel_f32_bvh") if args.precision == 32 else "render_kernel_f64<2>",
                 "kernel_ms_avg": round(kern_ms / max(1, len(stats)), 3),
                 "flops_per_segment": round(flops / max(seg, 1), 1),

@@ -16,10 +16,6 @@
 
 using namespace mirt;
 
-#ifndef MIRT_F32_MIN_WAVES
-#define MIRT_F32_MIN_WAVES 4 /* __launch_bounds__ waves per SIMD for the f32 render kernel (A/B on MI355X, profiles/r01_*ab*) */
-#endif
-
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
     g_err = msg;

@@ -7,11 +7,11 @@
  *   K3 quantize_kernel      stand-alone quantiser
  *   K4 deinterleave_kernel  gathered row bands -> frame
  *
- * Closest-hit query (`trace`): brute force over all spheres, as an n-body style tile loop.
- *   broad phase : every lane evaluates the discriminant d of sphere.rs:81-90 for every sphere; the sphere
- *                 records are staged per wave in LDS (one coalesced 16-B load per lane per 64 spheres) and
- *                 read back as wave-uniform broadcasts.  Lanes only remember WHICH spheres have d >= 0
- *                 (a short per-lane candidate list in LDS).
+ * Closest-hit query: brute force over all spheres, as an n-body style tile loop (`trace` f64, `trace_cons` f32),
+ * or - on request, f32 only - a bounding-volume tree (`trace_bvh`).
+ *   broad phase : every lane tests every sphere (f64: the discriminant d of sphere.rs:81-90; f32: a conservative
+ *                 bounding-ball test of 8 VALU); the records come from LDS as wave-uniform broadcasts.  Lanes only
+ *                 remember WHICH spheres may be hit (a short per-lane list in LDS).
  *   narrow phase: each lane then walks its own list and runs the exact root selection of sphere.rs:91-101
  *                 (sqrt, true divisions, strict interval) - a few iterations per lane instead of one
  *                 divergent slow path per (wave, sphere).
@@ -803,10 +803,6 @@ template <class R> __device__ inline R wave_sum_u(R v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-
-#ifndef MIRT_STATIC_SMEM
-#define MIRT_STATIC_SMEM true
-#endif
 
 /* ---- K1 ------------------------------------------------------------------------------------------ */
 template <class T>
