@@ -120,6 +120,7 @@ pub struct mirt_stats {
     pub wave_iterations: u64,
     pub nan_pixels: u64,
     pub kernel_ms: f64,
+    pub tree_segments: u64,
 }
 
 #[repr(C)]
@@ -135,7 +136,7 @@ const _: () = assert!(std::mem::size_of::<mirt_material>() == 64);
 const _: () = assert!(std::mem::size_of::<mirt_sphere>() == 64);
 const _: () = assert!(std::mem::size_of::<mirt_camera>() == 192);
 const _: () = assert!(std::mem::size_of::<mirt_opts>() == 32);
-const _: () = assert!(std::mem::size_of::<mirt_stats>() == 64);
+const _: () = assert!(std::mem::size_of::<mirt_stats>() == 72);
 
 extern "C" {
     pub fn mirt_abi_version() -> c_int;

@@ -139,13 +139,15 @@ typedef struct mirt_opts {
 /* Counters written by a render call (device-side exact counts). */
 typedef struct mirt_stats {
     uint64_t segments;        /* ray segments traced = closest-hit queries (camera.rs:273)        */
-    uint64_t sphere_tests;    /* static_tests + moving_tests                                      */
+    uint64_t sphere_tests;    /* static_tests + moving_tests: (ray, sphere) pairs of the brute-force loop  */
     uint64_t static_tests;
     uint64_t moving_tests;
     uint64_t narrow_tests;    /* candidates (d >= 0) that reached the root computation            */
     uint64_t wave_iterations; /* wave-level passes of the segment loop (64 lanes each)            */
     uint64_t nan_pixels;      /* pixels whose radiance was NaN (reference would panic)            */
     double kernel_ms;         /* hipEvent time of the dominant kernel, on the stream it ran on    */
+    uint64_t tree_segments;   /* of `segments`: traced through the bounding-volume tree (MIRT_FLAG_BVH);  */
+                              /* those are not counted in *_tests                                          */
 } mirt_stats;
 
 typedef struct mirt_scene mirt_scene; /* opaque: device-resident flattened scene */

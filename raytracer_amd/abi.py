@@ -94,6 +94,7 @@ class MirtStats(C.Structure):
         ("wave_iterations", C.c_uint64),
         ("nan_pixels", C.c_uint64),
         ("kernel_ms", C.c_double),
+        ("tree_segments", C.c_uint64),
     ]
 
     def asdict(self):

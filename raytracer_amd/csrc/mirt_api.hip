@@ -579,8 +579,10 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
             if (e != hipSuccess) rc = fail(MIRT_ERR_HIP, std::string("render: ") + hipGetErrorString(e));
             memset(stats, 0, sizeof(*stats));
             stats->segments = h.segments;
-            stats->static_tests = h.segments * (uint64_t)s->true_static;
-            stats->moving_tests = h.segments * (uint64_t)(s->true_n - s->true_static);
+            stats->tree_segments = (o->flags & MIRT_FLAG_BVH) ? h.segments : 0;
+            const uint64_t brute = h.segments - stats->tree_segments;
+            stats->static_tests = brute * (uint64_t)s->true_static;
+            stats->moving_tests = brute * (uint64_t)(s->true_n - s->true_static);
             stats->sphere_tests = stats->static_tests + stats->moving_tests;
             stats->narrow_tests = h.narrow;
             stats->wave_iterations = h.wave_iters;
