@@ -31,7 +31,6 @@ static int fail(int code, const std::string& msg) {
 template <class R> struct SceneBuffers {
     typename Vec4<R>::type *A = nullptr, *B = nullptr;
     DevMaterial<R>* mats = nullptr;
-    DevTexture<R>* texs = nullptr;
 };
 struct mirt_scene {
     int device = 0;
@@ -47,7 +46,6 @@ struct mirt_scene {
     uint32_t* bvh_idx = nullptr;
     uint32_t bvh_root = MIRT_BVH_NONE, bvh_n_nodes = 0, bvh_n_recs = 0, bvh_depth = 0;
     bool bvh_ok = false;
-    DevImage* imgs = nullptr;
     DevStats* stats = nullptr; /* one per scene: calls on one scene handle are not re-entrant */
     std::vector<void*> allocs;
     /* render workspace (per-item partial sums), grown on demand and kept until the scene is destroyed */
@@ -218,7 +216,8 @@ static int build_bvh(mirt_scene* s, std::vector<BallRec>& balls, const std::vect
 }
 
 template <class R>
-static int upload_real(mirt_scene* s, const mirt_scene_desc* d, const std::vector<uint32_t>& order, SceneBuffers<R>& out) {
+static int upload_real(mirt_scene* s, const mirt_scene_desc* d, const std::vector<uint32_t>& order, const std::vector<DevImage>& imgs,
+                       SceneBuffers<R>& out) {
     typedef typename Vec4<R>::type R4;
     std::vector<R4> A(order.size()), B(order.size());
     for (size_t k = 0; k < order.size(); ++k) {
@@ -240,31 +239,32 @@ static int upload_real(mirt_scene* s, const mirt_scene_desc* d, const std::vecto
     std::vector<DevMaterial<R>> mats(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const mirt_material& m = d->materials[i];
-        mats[i].kind = m.kind; mats[i].tex = m.texture; mats[i].has_fuzz = m.has_fuzz; mats[i].tex_kind = 0xFFFFFFFFu;
-        mats[i].reflectance = (R)m.reflectance; mats[i].fuzz = (R)m.fuzz; mats[i].ior = (R)m.ior;
-        mats[i].albedo = {(R)m.albedo[0], (R)m.albedo[1], (R)m.albedo[2]};
-        if (m.kind == MIRT_MAT_LAMBERTIAN) { /* validated above: m.texture < n_textures */
+        DevMaterial<R>& o = mats[i];
+        memset(&o, 0, sizeof(o));
+        o.kind = m.kind; o.has_fuzz = m.has_fuzz; o.tex_kind = 0xFFFFFFFFu;
+        o.reflectance = (R)m.reflectance; o.fuzz = (R)m.fuzz; o.ior = (R)m.ior;
+        o.albedo = {(R)m.albedo[0], (R)m.albedo[1], (R)m.albedo[2]};
+        if (m.kind == MIRT_MAT_LAMBERTIAN) { /* validated by the caller: texture and image indices are in range */
             const mirt_texture& t = d->textures[m.texture];
-            mats[i].tex_kind = t.kind;
-            if (t.kind == MIRT_TEX_SOLID) mats[i].albedo = {(R)t.color[0], (R)t.color[1], (R)t.color[2]};
+            o.tex_kind = t.kind;
+            o.inv_scale = (R)t.inv_scale;
+            if (t.kind != MIRT_TEX_IMAGE) {
+                o.albedo = {(R)t.color[0], (R)t.color[1], (R)t.color[2]};
+                o.odd = {(R)t.odd[0], (R)t.odd[1], (R)t.odd[2]};
+            } else {
+                o.img_w = imgs[t.image].w; o.img_h = imgs[t.image].h; o.img_offset = imgs[t.image].offset;
+            }
         }
     }
-    std::vector<DevTexture<R>> texs(d->n_textures);
-    for (uint32_t i = 0; i < d->n_textures; ++i) {
-        const mirt_texture& t = d->textures[i];
-        texs[i].kind = t.kind; texs[i].image = t.image; texs[i].inv_scale = (R)t.inv_scale;
-        texs[i].even = {(R)t.color[0], (R)t.color[1], (R)t.color[2]};
-        texs[i].odd = {(R)t.odd[0], (R)t.odd[1], (R)t.odd[2]};
-    }
     int rc;
-    if ((rc = upload(s, A, &out.A)) || (rc = upload(s, B, &out.B)) || (rc = upload(s, mats, &out.mats)) || (rc = upload(s, texs, &out.texs))) return rc;
+    if ((rc = upload(s, A, &out.A)) || (rc = upload(s, B, &out.B)) || (rc = upload(s, mats, &out.mats))) return rc;
     return MIRT_OK;
 }
 
 template <class R> static DevScene<R> dev_scene(const mirt_scene* s, const SceneBuffers<R>& b) {
     DevScene<R> d;
-    d.A = b.A; d.B = b.B; d.orig_id = s->orig_id; d.material = s->material; d.mats = b.mats; d.texs = b.texs;
-    d.imgs = s->imgs; d.texels = s->texels; d.n = s->n; d.n_static = s->n_static;
+    d.A = b.A; d.B = b.B; d.orig_id = s->orig_id; d.material = s->material; d.mats = b.mats;
+    d.texels = s->texels; d.n = s->n; d.n_static = s->n_static;
     d.S = sizeof(R) == 4 ? s->S : nullptr;
     d.n_materials = s->n_materials;
     d.bvh = s->bvh; d.bvh_S = s->bvh_S; d.bvh_idx = s->bvh_idx; d.bvh_root = s->bvh_root;
@@ -483,8 +483,8 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
             texels.push_back((uint32_t)im.rgb[3 * p] | ((uint32_t)im.rgb[3 * p + 1] << 8) | ((uint32_t)im.rgb[3 * p + 2] << 16));
     }
     int rc;
-    if ((rc = upload(s, order, &s->orig_id)) || (rc = upload(s, mat, &s->material)) || (rc = upload(s, imgs, &s->imgs)) ||
-        (rc = upload(s, texels, &s->texels)) || (rc = upload_real<float>(s, d, order, s->f32)) || (rc = upload_real<double>(s, d, order, s->f64))) {
+    if ((rc = upload(s, order, &s->orig_id)) || (rc = upload(s, mat, &s->material)) ||
+        (rc = upload(s, texels, &s->texels)) || (rc = upload_real<float>(s, d, order, imgs, s->f32)) || (rc = upload_real<double>(s, d, order, imgs, s->f64))) {
         mirt_scene_destroy(s);
         return rc;
     }

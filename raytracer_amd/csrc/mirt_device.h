@@ -55,6 +55,8 @@ __device__ inline float m_atan2(float y, float x) { return atan2f(y, x); }
 __device__ inline double m_atan2(double y, double x) { return atan2(y, x); }
 __device__ inline float m_sin(float x) { return sinf(x); }
 __device__ inline double m_sin(double x) { return sin(x); }
+__device__ inline void m_sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }
+__device__ inline void m_sincos(double x, double& s, double& c) { sincos(x, &s, &c); }
 __device__ inline float m_cos(float x) { return cosf(x); }
 __device__ inline double m_cos(double x) { return cos(x); }
 
@@ -72,16 +74,15 @@ struct DevImage {
     uint32_t offset; /* first texel in the RGBA8 pool (one dword per texel, A unused) */
     uint32_t _pad;
 };
-template <class R> struct DevTexture {
-    uint32_t kind, image;
-    R inv_scale;
-    V3<R> even, odd;
-};
+/* One self-contained record per material: the texture of a Lambertian (solid colour, checker colours and 1/scale, or the
+ * image's size and place in the texel pool) is folded in on the host, so a bounce costs ONE dependent fetch before the
+ * texel itself instead of material -> texture -> image -> texel. */
 template <class R> struct DevMaterial {
-    uint32_t kind, tex, has_fuzz;
-    uint32_t tex_kind; /* LAMBERTIAN: kind of its texture; a SolidColor's albedo is copied into `albedo` (one load less per bounce) */
-    R reflectance, fuzz, ior;
-    V3<R> albedo;
+    uint32_t kind, tex_kind, has_fuzz, img_w; /* tex_kind: LAMBERTIAN only */
+    uint32_t img_h, img_offset, _pad0, _pad1; /* IMAGE texture: size, first texel in the pool (img_h == 0: cyan, texture.rs:78-80) */
+    R reflectance, fuzz, ior, inv_scale;
+    V3<R> albedo; /* METAL albedo | SOLID colour | CHECKER even colour */
+    V3<R> odd;    /* CHECKER odd colour */
 };
 /* Node of the bounding-volume tree (MIRT_FLAG_BVH): the boxes of BOTH children, one 64-byte fetch per step.
  *   q0 = (lo0.x, lo0.y, lo0.z, hi0.x)  q1 = (hi0.y, hi0.z, lo1.x, lo1.y)  q2 = (lo1.z, hi1.x, hi1.y, hi1.z)
@@ -104,8 +105,6 @@ template <class R> struct DevScene {
     const uint32_t* orig_id;         /* sorted index -> hit id (index in mirt_scene_desc.spheres) */
     const uint32_t* material;        /* sorted index -> material                */
     const DevMaterial<R>* mats;
-    const DevTexture<R>* texs;
-    const DevImage* imgs;
     const uint32_t* texels;          /* RGBA8 pool                              */
     /* f32 only: conservative bounding record per sorted sphere for the broad phase, (M.x, M.y, M.z, w):
      * M = centre of the ball that contains the sphere over the whole shutter interval, w = |M|^2 - rho^2 - margin

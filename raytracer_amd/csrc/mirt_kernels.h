@@ -653,18 +653,16 @@ template <class R> __device__ inline uint32_t to_u32_sat(R x) { /* Rust `as u32`
     if (x >= (R)4294967295.0) return 0xFFFFFFFFu;
     return (uint32_t)x;
 }
-template <class R> __device__ inline V3<R> texture_color(const DevScene<R>& sc, uint32_t tex, const Hit<R>& h) {
-    const DevTexture<R>& t = sc.texs[tex];
-    if (t.kind == MIRT_TEX_SOLID) return t.even; /* texture.rs:24-28 */
-    if (t.kind == MIRT_TEX_CHECKER) {            /* texture.rs:46-59 */
-        uint32_t acc = (uint32_t)floor_to_i32(m_floor(h.p.x * t.inv_scale));
-        acc += (uint32_t)floor_to_i32(m_floor(h.p.y * t.inv_scale));
-        acc += (uint32_t)floor_to_i32(m_floor(h.p.z * t.inv_scale));
-        return (((int32_t)acc) % 2 == 0) ? t.even : t.odd;
+template <class R> __device__ inline V3<R> texture_color(const DevScene<R>& sc, const DevMaterial<R>& m, const Hit<R>& h) {
+    if (m.tex_kind == MIRT_TEX_SOLID) return m.albedo; /* texture.rs:24-28 */
+    if (m.tex_kind == MIRT_TEX_CHECKER) {              /* texture.rs:46-59 */
+        uint32_t acc = (uint32_t)floor_to_i32(m_floor(h.p.x * m.inv_scale));
+        acc += (uint32_t)floor_to_i32(m_floor(h.p.y * m.inv_scale));
+        acc += (uint32_t)floor_to_i32(m_floor(h.p.z * m.inv_scale));
+        return (((int32_t)acc) % 2 == 0) ? m.albedo : m.odd;
     }
     /* IMAGE: texture.rs:71-94 with (u,v) of sphere.rs:72-76 */
-    DevImage im = sc.imgs[t.image];
-    if (im.h == 0) return {(R)0.0, (R)1.0, (R)1.0};
+    if (m.img_h == 0) return {(R)0.0, (R)1.0, (R)1.0};
     const R PI = (R)3.14159265358979323846264338327950288;
     const R FRAC_1_PI = (R)0.318309886183790671537767526745028724;
     R theta = -m_acos(h.on.y);
@@ -674,11 +672,11 @@ template <class R> __device__ inline V3<R> texture_color(const DevScene<R>& sc, 
     u = u < (R)0.0 ? (R)0.0 : (u > (R)1.0 ? (R)1.0 : u);
     v = m_fabs(v);
     v = v < (R)0.0 ? (R)0.0 : (v > (R)1.0 ? (R)1.0 : v);
-    uint32_t i = to_u32_sat(u * (R)im.w);
-    uint32_t j = to_u32_sat(v * (R)im.h);
-    i = i < im.w - 1 ? i : im.w - 1;
-    j = j < im.h - 1 ? j : im.h - 1;
-    uint32_t px = sc.texels[im.offset + j * im.w + i];
+    uint32_t i = to_u32_sat(u * (R)m.img_w);
+    uint32_t j = to_u32_sat(v * (R)m.img_h);
+    i = i < m.img_w - 1 ? i : m.img_w - 1;
+    j = j < m.img_h - 1 ? j : m.img_h - 1;
+    uint32_t px = sc.texels[m.img_offset + j * m.img_w + i];
     return {(R)(px & 0xFFu) / (R)255.0, (R)((px >> 8) & 0xFFu) / (R)255.0, (R)((px >> 16) & 0xFFu) / (R)255.0};
 }
 
@@ -713,7 +711,7 @@ __device__ inline bool scatter(const DevScene<R>& sc, uint32_t mat, const RayT<R
         const R e = (R)1e-8;
         if (m_fabs(dir.x) < e && m_fabs(dir.y) < e && m_fabs(dir.z) < e) dir = hit.n;
         out = {hit.p, dir, rin.tm};
-        att = (m.tex_kind == MIRT_TEX_SOLID ? m.albedo : texture_color(sc, m.tex, hit)) / m.reflectance;
+        att = texture_color(sc, m, hit) / m.reflectance;
         return true;
     }
     if (m.kind == MIRT_MAT_METAL) { /* material.rs:97-114; dims 0..2 = vector */
@@ -748,7 +746,9 @@ template <class R> __device__ inline RayT<R> ray_for(const DevCamera<R>& c, uint
         const R TAU = (R)6.28318530717958647692528676655900577;
         R r = m_sqrt(uc);
         R th = ud * TAU;
-        R dx = r * m_cos(th), dy = r * m_sin(th);
+        R sn, cs;
+        m_sincos(th, sn, cs); /* one range reduction for both */
+        R dx = r * cs, dy = r * sn;
         orig = c.lookfrom + (c.disk_u * dx) + (c.disk_v * dy);
     }
     return {orig, px - orig, ue};
