@@ -103,3 +103,59 @@ def test_bvh_flag_is_f32_only():
     with pytest.raises(abi.MirtError) as e:
         cam.primary_hits(sc, precision=abi.F64, accel="bvh")
     assert e.value.code == -1  # MIRT_ERR_INVALID
+
+
+def test_bvh_equals_brute_force_at_full_size_c5():
+    """BASELINE.json configs[4] size: 10 000 spheres at 3840x2160, every primary ray through both closest-hit
+    implementations (the oracle would need hours for this map; the two kernels share only the exact narrow test)."""
+    sc = presets.stress_scene(10000, seed=1)
+    cam = presets.stress_camera(3840, 0, 50)
+    ids, t = cam.primary_hits(sc, precision=abi.F32, accel="bvh")
+    b_ids, b_t = cam.primary_hits(sc, precision=abi.F32)
+    assert ids.shape == (2160, 3840)
+    assert np.array_equal(ids, b_ids) and np.array_equal(bits(t), bits(b_t))
+    assert len(np.unique(ids)) > 3000
+
+
+def test_bvh_image_independent_of_partition():
+    """MIRT_FLAG_BVH with the multi-GPU partition options: bands of 1/2/3 parts reassemble to the same frame."""
+    import ctypes as C
+
+    import torch
+
+    from raytracer_amd import dist
+
+    sc = presets.bouncing_balls_scene(1)
+    cam = presets.bouncing_balls_camera(96, 4, 10)
+    ref, _ = cam.render_arrays(sc, precision=abi.F32, seed=3, accel="bvh")
+    lib = abi.load()
+    ds = sc.device_scene(0)
+    H, W, S = cam.height, cam.width, 8
+    for parts in (2, 3):
+        rows0 = dist.part_rows(H, S, 0, parts)
+        bands = torch.zeros((parts, rows0, W, 3), dtype=torch.float32, device="cuda")
+        for r in range(parts):
+            o = cam.opts(precision=abi.F32, seed=3, strip_rows=S, part_index=r, part_count=parts, flags=abi.FLAG_COMPACT_ROWS | abi.FLAG_BVH)
+            abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(o), bands[r].data_ptr(), None, None, None))
+        torch.cuda.synchronize()
+        frame = dist.deinterleave_host(bands.cpu().numpy(), H, S)
+        assert np.array_equal(bits(frame), bits(ref))
+
+
+def test_bvh_degenerate_spheres_and_camera_inside(oracle):
+    """Zero and negative radii (stored as max(r, 0), sphere.rs:31), a sphere around the camera, concentric duplicates."""
+    sc = Scene()
+    m = Lambertian.new((1, 1, 1), 1.0)
+    sc.add(Sphere.new_static(0.0, (0.0, 0.0, -3.0), m))
+    sc.add(Sphere.new_static(-1.0, (0.5, 0.0, -3.0), m))
+    sc.add(Sphere.new_static(50.0, (0.0, 0.0, 0.0), Dielectric.new(1.5)))  # the camera sits inside
+    sc.add(Sphere.new(0.5, (0.0, 0.0, -4.0), (0.0, 0.0, -4.0), m))
+    sc.add(Sphere.new_static(0.5, (0.0, 0.0, -4.0), m))
+    sc.add(Sphere.new_static(1.0, (2.0, 0.0, -6.0), Metal.new((1, 1, 1), 0.0)))
+    sc.build_bvh()
+    cam = Camera.build(None, None, None, 48, 1.0, 0, None, None, None, 10)
+    ids = _same_maps(oracle, sc, cam)
+    assert 3 in ids and 4 not in ids  # the static twin (id 4) loses the tie to the moving one (id 3)
+    a, _ = Camera.build(None, None, None, 48, 1.0, 3, None, None, None, 10).render_arrays(sc, precision=abi.F32, seed=1, accel="bvh")
+    b, _ = Camera.build(None, None, None, 48, 1.0, 3, None, None, None, 10).render_arrays(sc, precision=abi.F32, seed=1)
+    assert np.array_equal(bits(a), bits(b))
