@@ -376,6 +376,7 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     rp.d_chunks = make_fastdiv(rp.chunks);
     rp.d_W = make_fastdiv(cam->img_width);
     rp.d_strip = make_fastdiv(part.strip_rows);
+    rp.keep_num = 0;
     size_t need = (size_t)rp.n_items * 3 * sizeof(R);
     if (need > s->partial_bytes) {
         if (s->partial) (void)hipFree(s->partial);
@@ -396,6 +397,10 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
         uint64_t grid = std::min<uint64_t>((uint64_t)s->n_cus * per_cu, (waves_needed + waves_per_block - 1) / waves_per_block);
         /* the last two full batches per wave are handed out one item per lane at a time */
         rp.tail_items = (uint32_t)std::min<uint64_t>(grid * waves_per_block * 2 * MIRT_QUEUE_BATCH, rp.n_items);
+        if (bvh) { /* suspend a traversal once this share (in 64ths) of the traversing lanes is all that is left (tuning knob: MIRT_BVH_KEEP, 0..64) */
+            rp.keep_num = bvh == 1 ? 32 : 16; /* measured: profiles/r01_microbench.txt */
+            if (const char* e = getenv("MIRT_BVH_KEEP")) rp.keep_num = (uint32_t)std::min(64, std::max(0, atoi(e)));
+        }
         launch_render_kernel((uint32_t)grid, block, bvh, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, rp, (R*)s->partial, s->stats);
         HIP_TRY(hipGetLastError());
     }

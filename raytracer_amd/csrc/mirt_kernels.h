@@ -488,11 +488,15 @@ struct BvhLdsStore {
     __device__ inline Geom geom() const { return Geom{L}; }
 };
 
+/* A traversal can be suspended and resumed: its state is the node in hand, the stack depth (the stack itself lives in
+ * LDS) and the best hit so far.  `keep` = the number of lanes of the wave that must still be traversing for the loop to
+ * go on; 1 runs every lane to completion. */
+struct BvhState {
+    uint32_t cur, sp;
+};
 template <class Store>
-__device__ inline void trace_bvh(const DevScene<float>& sc, const Store& store, uint32_t (*stk)[MIRT_WAVE], uint32_t lane, bool active, const RayT<float>& ray,
-                                 float tmin, Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
-    best.t = INFINITY;
-    best.idx = 0xFFFFFFFFu;
+__device__ inline void trace_bvh_resume(const DevScene<float>& sc, const Store& store, uint32_t (*stk)[MIRT_WAVE], uint32_t lane, const RayT<float>& ray,
+                                        float tmin, Closest<float>& best, BvhState& st, uint32_t keep, uint32_t& narrow_count, PhaseTimer& pt) {
     const V3<float> O = ray.o;
     const float a_true = ray_a(ray.d);
     const float inv = 1.0f / sqrtf(a_true);
@@ -511,11 +515,13 @@ __device__ inline void trace_bvh(const DevScene<float>& sc, const Store& store, 
     };
     const V3<float> iD = {cap_inv(ray.d.x), cap_inv(ray.d.y), cap_inv(ray.d.z)};
     const float tmin_dn = tmin * 0.99999f;
-    float best_up = INFINITY;
-    uint32_t cur = active ? sc.bvh_root : MIRT_BVH_NONE, sp = 0;
+    float best_up = best.t * 1.00001f;
+    uint32_t cur = st.cur, sp = st.sp;
     /* "while-while": all lanes first walk inner nodes until each holds a leaf (or nothing), then the leaves are
      * processed together */
-    while (__ballot(cur != MIRT_BVH_NONE) != 0ull) {
+    for (;;) {
+        const uint32_t live = (uint32_t)__popcll(__ballot(cur != MIRT_BVH_NONE));
+        if (live == 0 || live < keep) break;
         while (__ballot(cur != MIRT_BVH_NONE && !(cur & 0x80000000u)) != 0ull) {
 #ifdef MIRT_BVH_COUNTERS
             if (lane == 0) atomicAdd((unsigned long long*)sc.dbg + 6, 1ull);
@@ -582,7 +588,17 @@ __device__ inline void trace_bvh(const DevScene<float>& sc, const Store& store, 
             if (sp > 0) cur = stk[--sp][lane];
         }
     }
+    st.cur = cur;
+    st.sp = sp;
     pt.stamp(PH_BROAD);
+}
+template <class Store>
+__device__ inline void trace_bvh(const DevScene<float>& sc, const Store& store, uint32_t (*stk)[MIRT_WAVE], uint32_t lane, bool active, const RayT<float>& ray,
+                                 float tmin, Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+    best.t = INFINITY;
+    best.idx = 0xFFFFFFFFu;
+    BvhState st{active ? sc.bvh_root : MIRT_BVH_NONE, 0u};
+    trace_bvh_resume(sc, store, stk, lane, ray, tmin, best, st, 1u, narrow_count, pt);
 }
 
 /* ---- hit record of the winner: sphere.rs:102-107, hittable.rs:48-60 -------------------------------- */
@@ -606,6 +622,7 @@ template <class R, class G> __device__ inline Hit<R> make_hit(const DevScene<R>&
 /* ---- closest-hit front ends used by the kernels: f64 = exact broad phase, f32 = conservative broad phase ---- */
 struct TracerF64 {
     typedef double Real;
+    static constexpr bool RESUMABLE = false;
     const DevScene<double>& sc;
     WaveLds<double>& lds;
     __device__ inline void closest(uint32_t lane, bool active, const RayT<double>& ray, double tmin, Closest<double>& best, uint32_t& nc, PhaseTimer& pt) {
@@ -616,6 +633,7 @@ struct TracerF64 {
 };
 template <bool RES> struct TracerF32 {
     typedef float Real;
+    static constexpr bool RESUMABLE = false;
     const DevScene<float>& sc;
     F32Lds& L;
     uint32_t w;
@@ -629,13 +647,18 @@ template <bool RES> struct TracerF32 {
     __device__ inline uint32_t material(uint32_t idx) const { return RES ? (uint32_t)L.mat[idx] : sc.material[idx]; }
 };
 
-template <class Store> struct TracerF32Bvh {
+template <class Store, bool DYN> struct TracerF32Bvh {
     typedef float Real;
+    static constexpr bool RESUMABLE = DYN; /* render_body may leave a traversal half-way to refill finished lanes */
     const DevScene<float>& sc;
     Store store;
     uint32_t (*stk)[MIRT_WAVE];
     __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
         trace_bvh(sc, store, stk, lane, active, ray, tmin, best, nc, pt);
+    }
+    __device__ inline void resume(uint32_t lane, const RayT<float>& ray, float tmin, Closest<float>& best, BvhState& st, uint32_t keep, uint32_t& nc,
+                                  PhaseTimer& pt) {
+        trace_bvh_resume(sc, store, stk, lane, ray, tmin, best, st, keep, nc, pt);
     }
     __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const { return make_hit(sc, store.geom(), c, ray); }
     __device__ inline uint32_t material(uint32_t idx) const { return store.geom().material(idx); }
@@ -849,7 +872,7 @@ __global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel_f32_bvh(DevSce
                                                                           float* __restrict__ out_t) {
     __shared__ uint32_t stk[MIRT_WAVES_PER_BLOCK][MIRT_BVH_STACK][MIRT_WAVE];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    TracerF32Bvh<BvhGlobalStore> tr{sc, BvhGlobalStore{sc}, stk[w]};
+    TracerF32Bvh<BvhGlobalStore, false> tr{sc, BvhGlobalStore{sc}, stk[w]};
     primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_WAVES_PER_BLOCK + w, lane, out_id, out_t);
 }
 
@@ -870,6 +893,7 @@ struct RenderParams {
     uint32_t k0, k1;     /* RNG key */
     uint32_t tail_items; /* queue tail served in batches of one item per lane (guided self-scheduling) */
     FastDiv d_chunks, d_W, d_strip; /* divisions by chunks, image width and strip height when an item is decoded */
+    uint32_t keep_num;   /* resumable tree traversal: go on while >= keep_num/64 of the traversing lanes are still at it (0: run to the end) */
 };
 
 template <class T>
@@ -887,6 +911,10 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
     V3<R> acc = {(R)0.0, (R)0.0, (R)0.0}, thr = {(R)1.0, (R)1.0, (R)1.0};
     RayT<R> ray = {};
     uint32_t n_seg = 0, n_narrow = 0, n_iter = 0;
+    /* resumable traversal (T::RESUMABLE): a lane's query may span several iterations of the loop below */
+    bool traversing = false;
+    BvhState trav = {MIRT_BVH_NONE, 0u};
+    Closest<R> pbest = {(R)INFINITY, 0xFFFFFFFFu};
     PhaseTimer pt;
     pt.start();
 #ifdef MIRT_PHASE_TIMING
@@ -960,8 +988,28 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
         pt.stamp(PH_RAYGEN);
         /* ---- one ray segment for every lane of the wave ---------------------------------------------- */
         Closest<R> best;
-        tr.closest(lane, has_work, ray, (R)0.001, best, n_narrow, pt);
-        if (has_work) {
+        bool seg_done; /* this lane's closest-hit query completed in this iteration */
+        if constexpr (T::RESUMABLE) {
+            /* Lanes of a wave need very different numbers of tree steps (2-5x the mean for the slowest), and a step costs
+             * the same whether 64 lanes take it or 3.  So a query is suspended as soon as a good share of the wave's
+             * lanes have finished theirs: those are shaded, given their next ray (or item), and join the rest again. */
+            if (has_work && !traversing) { /* a fresh ray: from the camera or from the last scatter */
+                trav = {sc.bvh_root, 0u};
+                pbest = {(R)INFINITY, 0xFFFFFFFFu};
+                traversing = true;
+            }
+            const uint32_t n_trav = (uint32_t)__popcll(__ballot(traversing));
+            uint32_t keep = (n_trav * rp.keep_num) >> 6;
+            keep = (keep < 1u || (exhausted && q_next == q_end)) ? 1u : keep;
+            tr.resume(lane, ray, (R)0.001, pbest, trav, keep, n_narrow, pt);
+            seg_done = traversing && trav.cur == MIRT_BVH_NONE;
+            traversing = traversing && !seg_done;
+            best = pbest;
+        } else {
+            tr.closest(lane, has_work, ray, (R)0.001, best, n_narrow, pt);
+            seg_done = has_work;
+        }
+        if (seg_done) {
             ++n_seg;
             bool done;
             V3<R> radiance = {(R)0.0, (R)0.0, (R)0.0};
@@ -1033,7 +1081,7 @@ __global__ __launch_bounds__(MIRT_BLOCK) void render_kernel_f32_bvh(DevScene<flo
                                                                     float* __restrict__ partial, DevStats* __restrict__ stats) {
     __shared__ uint32_t stk[MIRT_WAVES_PER_BLOCK][MIRT_BVH_STACK][MIRT_WAVE];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    TracerF32Bvh<BvhGlobalStore> tr{sc, BvhGlobalStore{sc}, stk[w]};
+    TracerF32Bvh<BvhGlobalStore, true> tr{sc, BvhGlobalStore{sc}, stk[w]};
     render_body(tr, sc, cam, part, rp, partial, stats, lane);
 }
 /* the same for scenes whose tree, records and spheres fit the LDS: one block of 16 waves per CU, no HBM in the loop */
@@ -1042,7 +1090,7 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK) void render_kernel_f32_bvh_lds(DevS
     __shared__ BvhLds L;
     L.fill(sc);
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    TracerF32Bvh<BvhLdsStore> tr{sc, BvhLdsStore{L}, L.stk[w]};
+    TracerF32Bvh<BvhLdsStore, true> tr{sc, BvhLdsStore{L}, L.stk[w]};
     render_body(tr, sc, cam, part, rp, partial, stats, lane);
 }
 /* one block of 16 waves per CU: 4 waves per SIMD, <= 128 VGPRs */
