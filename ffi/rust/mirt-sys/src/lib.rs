@@ -26,6 +26,7 @@ pub const MIRT_F64: u32 = 64;
 pub const MIRT_F32: u32 = 32;
 pub const MIRT_FLAG_COMPACT_ROWS: u32 = 1;
 pub const MIRT_FLAG_BVH: u32 = 2;
+pub const MIRT_FLAG_VALU_BROAD: u32 = 4;
 
 #[repr(C)]
 #[derive(Clone, Copy)]

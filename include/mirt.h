@@ -123,6 +123,10 @@ typedef enum mirt_precision {
  * precision only).  Same (id, t) for every ray, hence the same image bit for bit; the counterpart of the reference's
  * Bvh::hit (src/scene/bvh.rs:78-92) for scenes where testing every sphere is not affordable. */
 #define MIRT_FLAG_BVH 2u
+/* f32 brute-force loop: keep the broad phase on the vector ALU.  By default scenes of <= 1024 spheres whose extents fit
+ * the split-f16 operands run the broad phase's dot products on the matrix pipe (v_mfma_f32_32x32x16_f16); the candidates
+ * go through the same exact test either way, so the (id, t) of every ray - and the image - do not depend on this flag. */
+#define MIRT_FLAG_VALU_BROAD 4u
 
 /* Which rows a call renders: rows are grouped in strips of `strip_rows`; strip s is owned when
  * s % part_count == part_index (interleaved strips).  part_count <= 1 = whole image. */

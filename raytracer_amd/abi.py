@@ -11,6 +11,7 @@ MISS_ID = 0xFFFFFFFF
 F64, F32 = 64, 32
 FLAG_COMPACT_ROWS = 1
 FLAG_BVH = 2  # closest hit through the bounding-ball tree (f32 only); same image bit for bit
+FLAG_VALU_BROAD = 4  # f32 brute force: broad phase on the vector ALU instead of the matrix pipe; same image bit for bit
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 

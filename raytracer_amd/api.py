@@ -304,6 +304,12 @@ def f64_to_u32(value: float) -> Optional[int]:
     return int(value)  # truncation toward zero, like `as u32`
 
 
+def _accel_flags(accel):
+    if accel not in (None, "brute", "bvh", "valu"):
+        raise ValueError(f"unknown accel {accel!r}")
+    return abi.FLAG_BVH if accel == "bvh" else abi.FLAG_VALU_BROAD if accel == "valu" else 0
+
+
 @dataclass
 class Camera:
     pod: abi.MirtCamera
@@ -389,14 +395,15 @@ class Camera:
     # -- the hot path: everything below runs in the HIP library -------------------------------------
     def render_arrays(self, scene: Scene, precision=None, seed=None, want_linear=True, want_rgb8=True, accel=None):
         """Camera::render without the text emission: returns (linear (H,W,3) real | None, rgb8 (H,W,3) u8 | None).
-        accel="bvh" traverses the bounding-ball tree (abi.FLAG_BVH, f32 only) instead of testing every sphere."""
+        accel="bvh" traverses the bounding-ball tree (abi.FLAG_BVH, f32 only) instead of testing every sphere;
+        accel="valu" keeps the brute-force broad phase on the vector ALU (abi.FLAG_VALU_BROAD)."""
         ds = scene.device_scene(self.device)
         prec = self.precision if precision is None else precision
         H, W = self.height, self.width
         lin = np.empty((H, W, 3), dtype=np.float64 if prec == abi.F64 else np.float32) if want_linear else None
         rgb8 = np.empty((H, W, 3), dtype=np.uint8) if want_rgb8 else None
         st = abi.MirtStats()
-        o = self.opts(precision=prec, seed=seed, flags=abi.FLAG_BVH if accel == "bvh" else 0)
+        o = self.opts(precision=prec, seed=seed, flags=_accel_flags(accel))
         abi.check(
             abi.load().mirt_render(
                 ds.handle, C.byref(self.pod), C.byref(o),
@@ -413,7 +420,7 @@ class Camera:
         H, W = self.height, self.width
         ids = np.empty((H, W), dtype=np.uint32)
         t = np.empty((H, W), dtype=np.float64 if prec == abi.F64 else np.float32)
-        o = self.opts(precision=prec, flags=abi.FLAG_BVH if accel == "bvh" else 0)
+        o = self.opts(precision=prec, flags=_accel_flags(accel))
         abi.check(abi.load().mirt_primary_hits(ds.handle, C.byref(self.pod), C.byref(o), ids.ctypes.data, t.ctypes.data))
         return ids, t
 

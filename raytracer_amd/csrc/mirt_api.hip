@@ -46,6 +46,9 @@ struct mirt_scene {
     uint32_t* bvh_idx = nullptr;
     uint32_t bvh_root = MIRT_BVH_NONE, bvh_n_nodes = 0, bvh_n_recs = 0, bvh_depth = 0;
     bool bvh_ok = false;
+    uint4* SM = nullptr;   /* split-f16 sphere operands of the matrix-pipe broad phase (trace_mx) */
+    float mx_scale = 1.f;  /* power of two: max (|M| + rho) * mx_scale <= 64 */
+    bool mx_ok = false;    /* resident, finite and inside the f16 range */
     DevStats* stats = nullptr; /* one per scene: calls on one scene handle are not re-entrant */
     std::vector<void*> allocs;
     /* render workspace (per-item partial sums), grown on demand and kept until the scene is destroyed */
@@ -261,6 +264,74 @@ static int upload_real(mirt_scene* s, const mirt_scene_desc* d, const std::vecto
     return MIRT_OK;
 }
 
+/* ---- matrix-pipe broad phase (trace_mx): split-f16 sphere operands -----------------------------------------
+ * Per tile of 32 sorted spheres 64 x 16 B: lane l carries K half (l / 32) of the sphere in MFMA row (l % 32); row i
+ * holds sorted sphere 32 T + 16 ((i / 4) % 2) + (i % 4) + 4 (i / 8), so that the 16 rows a result lane receives are 16
+ * consecutive spheres.  Values are in the scene scale 2^e with max (|M| + rho) 2^e <= 64. */
+static uint16_t f16_bits(_Float16 h) { uint16_t b; memcpy(&b, &h, 2); return b; }
+static _Float16 f16_from_bits(uint16_t b) { _Float16 h; memcpy(&h, &b, 2); return h; }
+static _Float16 f16_round_down(double x) { /* the largest f16 <= x (finite range) */
+    _Float16 h = (_Float16)x;
+    if ((double)h <= x) return h;
+    uint16_t b = f16_bits(h);
+    if ((b & 0x7FFFu) == 0) return f16_from_bits(0x8001u); /* below +-0: the smallest negative subnormal */
+    return f16_from_bits((b & 0x8000u) ? (uint16_t)(b + 1) : (uint16_t)(b - 1));
+}
+struct MxBall { double M[3]; double rho; bool real; };
+static int build_mx(mirt_scene* s, const std::vector<MxBall>& balls /* one per sorted slot */) {
+    s->mx_ok = false;
+    if (balls.size() > MIRT_LDS_RECORDS || s->n_materials > 0x10000u) return MIRT_OK;
+    double R = 0;
+    for (const MxBall& b : balls)
+        if (b.real) {
+            const double ext = std::sqrt(b.M[0] * b.M[0] + b.M[1] * b.M[1] + b.M[2] * b.M[2]) + b.rho;
+            if (!(ext < 1e30)) return MIRT_OK; /* NaN / inf / absurd extents: the VALU kernel copes, f16 does not */
+            R = std::max(R, ext);
+        }
+    if (!(R < 1e30)) return MIRT_OK; /* NaN / inf / absurd extents: the VALU kernel copes, f16 does not */
+    int e = 0;
+    if (R > 0) {
+        (void)std::frexp(64.0 / R, &e); /* 64 / R = m 2^e, m in [0.5, 1) -> 2^(e-1) <= 64 / R */
+        e -= 1;
+    }
+    e = std::max(-100, std::min(100, e));
+    const double sc = std::ldexp(1.0, e);
+    s->mx_scale = (float)sc;
+    const double eps = 1.0 / 16777216.0, F = 1.0 / 1048576.0; /* 2^-24, 2^-20 */
+    const size_t ntiles = (balls.size() + 31) / 32;
+    std::vector<uint4> SM(ntiles * 64);
+    for (size_t T = 0; T < ntiles; ++T)
+        for (uint32_t l = 0; l < 64; ++l) {
+            const uint32_t i = l % 32, sub = (i / 4) % 2, r = (i % 4) + 4 * (i / 8);
+            const size_t idx = 32 * T + 16 * sub + r;
+            _Float16 mh[3] = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f}, ml[3] = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            _Float16 wh = (_Float16)60000.0f, wl = (_Float16)0.f; /* dummy: q <= |O|^2 - 60000 < 0 for every admissible ray */
+            if (idx < balls.size() && balls[idx].real) {
+                const MxBall& b = balls[idx];
+                double M2 = 0;
+                for (int a = 0; a < 3; ++a) {
+                    const double m = b.M[a] * sc; /* exact: power of two */
+                    mh[a] = (_Float16)m;
+                    ml[a] = (_Float16)(m - (double)mh[a]);
+                    M2 += m * m;
+                }
+                const double rho = b.rho * sc, Ml = std::sqrt(M2);
+                const double w = M2 - rho * rho - 256.0 * eps * (M2 + rho * rho) - F * (1.0 + Ml);
+                wh = (_Float16)w;
+                wl = f16_round_down(w - (double)wh); /* wh + wl <= w */
+            }
+            _Float16 v[8];
+            const _Float16 one = (_Float16)1.0f;
+            if (l < 32) { v[0] = mh[0]; v[1] = ml[0]; v[2] = mh[0]; v[3] = ml[0]; v[4] = mh[1]; v[5] = ml[1]; v[6] = mh[1]; v[7] = ml[1]; }
+            else        { v[0] = mh[2]; v[1] = ml[2]; v[2] = mh[2]; v[3] = ml[2]; v[4] = one;   v[5] = one;   v[6] = wh;    v[7] = wl; }
+            memcpy(&SM[T * 64 + l], v, 16);
+        }
+    int rc;
+    if ((rc = upload(s, SM, &s->SM))) return rc;
+    s->mx_ok = true;
+    return MIRT_OK;
+}
+
 template <class R> static DevScene<R> dev_scene(const mirt_scene* s, const SceneBuffers<R>& b) {
     DevScene<R> d;
     d.A = b.A; d.B = b.B; d.orig_id = s->orig_id; d.material = s->material; d.mats = b.mats;
@@ -269,6 +340,7 @@ template <class R> static DevScene<R> dev_scene(const mirt_scene* s, const Scene
     d.n_materials = s->n_materials;
     d.bvh = s->bvh; d.bvh_S = s->bvh_S; d.bvh_idx = s->bvh_idx; d.bvh_root = s->bvh_root;
     d.bvh_n_nodes = s->bvh_n_nodes; d.bvh_n_recs = s->bvh_n_recs; d.bvh_depth = s->bvh_depth;
+    d.SM = s->SM; d.mx_scale = s->mx_scale;
     d.dbg = s->stats ? &s->stats->broad_misses : nullptr;
     return d;
 }
@@ -301,6 +373,17 @@ static int check_common(const mirt_scene* s, const mirt_camera* cam, const mirt_
     }
     return MIRT_OK;
 }
+/* The matrix-pipe broad phase serves resident scenes whose rays stay inside the f16 range of the scaled operands: rays
+ * start at the lens or on a sphere (|O| <= max(|M| + rho) = 64 scaled), so only the camera position has to be checked.
+ * (A ray outside the range is still traced correctly - it keeps every sphere as a candidate - but slowly.) */
+static bool use_mx(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o) {
+    if (o->precision != MIRT_F32 || (o->flags & (MIRT_FLAG_BVH | MIRT_FLAG_VALU_BROAD)) || !s->mx_ok) return false;
+    if (const char* e = getenv("MIRT_BROAD")) /* tuning knob: valu | matrix */
+        if (!strcmp(e, "valu")) return false;
+    auto len = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    const double reach = (len(cam->lookfrom) + len(cam->disk_u_r) + len(cam->disk_v_r)) * (double)s->mx_scale;
+    return reach <= 180.0; /* 180^2 < MIRT_MX_K2MAX; false for NaN */
+}
 static uint32_t grid_for(uint32_t W, uint32_t local_rows, uint32_t waves_per_block) {
     uint32_t tiles = ((W + 7) / 8) * ((local_rows + 7) / 8);
     return (tiles + waves_per_block - 1) / waves_per_block;
@@ -316,10 +399,12 @@ static int launch_primary(const mirt_scene* s, const SceneBuffers<double>& b, co
     return MIRT_OK;
 }
 static int launch_primary(const mirt_scene* s, const SceneBuffers<float>& b, const mirt_camera* cam, const DevPart& part, uint32_t* d_id, void* d_t,
-                          hipStream_t st, bool bvh = false) {
+                          hipStream_t st, bool bvh = false, bool mx = false) {
     uint32_t grid = grid_for(cam->img_width, part.local_rows, bvh ? MIRT_WAVES_PER_BLOCK : MIRT_F32_WAVES);
     if (grid == 0) return MIRT_OK;
-    if (bvh)
+    if (mx)
+        hipLaunchKernelGGL(primary_hits_kernel_f32_mx, dim3(grid), dim3(MIRT_F32_BLOCK), 0, st, dev_scene<float>(s, b), dev_camera<float>(cam), part, d_id, (float*)d_t);
+    else if (bvh)
         hipLaunchKernelGGL(primary_hits_kernel_f32_bvh, dim3(grid), dim3(MIRT_BLOCK), 0, st, dev_scene<float>(s, b), dev_camera<float>(cam), part, d_id, (float*)d_t);
     else
         hipLaunchKernelGGL(primary_hits_kernel_f32, dim3(grid), dim3(MIRT_F32_BLOCK), 0, st, dev_scene<float>(s, b), dev_camera<float>(cam), part, d_id, (float*)d_t);
@@ -343,23 +428,25 @@ static void choose_chunks(uint64_t n_pixels, uint32_t nsamples, size_t real_byte
 
 /* the two render kernels behind one name */
 static const void* render_fn(double, int) { return (const void*)render_kernel_f64<2>; }
-static const void* render_fn(float, int bvh) { return bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
+static const void* render_fn(float, int bvh) { return bvh == 3 ? (const void*)render_kernel_f32_mx : bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
 static void launch_render_kernel(uint32_t grid, uint32_t block, int, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam,
                                  const DevPart& part, const RenderParams& rp, double* partial, DevStats* stats) {
     hipLaunchKernelGGL(render_kernel_f64<2>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
 }
 static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<float>& sc, const DevCamera<float>& cam,
                                  const DevPart& part, const RenderParams& rp, float* partial, DevStats* stats) {
-    if (bvh == 2) hipLaunchKernelGGL(render_kernel_f32_bvh_lds, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    if (bvh == 3) hipLaunchKernelGGL(render_kernel_f32_mx, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    else if (bvh == 2) hipLaunchKernelGGL(render_kernel_f32_bvh_lds, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh) hipLaunchKernelGGL(render_kernel_f32_bvh, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else hipLaunchKernelGGL(render_kernel_f32, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
 }
 
 template <class R>
 static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mirt_camera* cam, const DevPart& part, uint64_t seed, void* d_lin,
-                         uint8_t* d_rgb8, hipStream_t st, bool use_bvh) {
-    /* tree traversal: 0 = no, 1 = tree in HBM/L2, 2 = tree, records and spheres resident in LDS */
-    const int bvh = !use_bvh ? 0
+                         uint8_t* d_rgb8, hipStream_t st, bool use_bvh, bool mx) {
+    /* closest-hit front end: 0 = brute force, VALU broad phase; 1 = tree in HBM/L2; 2 = tree, records and spheres resident in
+     * LDS; 3 = brute force, broad phase on the matrix pipe */
+    const int bvh = mx ? 3 : !use_bvh ? 0
                     : (s->bvh_n_nodes <= MIRT_BVH_LDS_NODES && s->bvh_n_recs <= MIRT_LDS_RECORDS && s->n <= MIRT_LDS_RECORDS &&
                        s->bvh_depth <= MIRT_BVH_LDS_STACK && s->n_materials <= 0x10000u && s->bvh_root != MIRT_BVH_NONE) ? 2 : 1;
     const uint32_t block = (sizeof(R) == 4 && bvh != 1) ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;
@@ -397,7 +484,7 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
         uint64_t grid = std::min<uint64_t>((uint64_t)s->n_cus * per_cu, (waves_needed + waves_per_block - 1) / waves_per_block);
         /* the last two full batches per wave are handed out one item per lane at a time */
         rp.tail_items = (uint32_t)std::min<uint64_t>(grid * waves_per_block * 2 * MIRT_QUEUE_BATCH, rp.n_items);
-        if (bvh) { /* suspend a traversal once this share (in 64ths) of the traversing lanes is all that is left (tuning knob: MIRT_BVH_KEEP, 0..64) */
+        if (bvh == 1 || bvh == 2) { /* suspend a traversal once this share (in 64ths) of the traversing lanes is all that is left (tuning knob: MIRT_BVH_KEEP, 0..64) */
             rp.keep_num = bvh == 1 ? 32 : 16; /* measured: profiles/r01_microbench.txt */
             if (const char* e = getenv("MIRT_BVH_KEEP")) rp.keep_num = (uint32_t)std::min(64, std::max(0, atoi(e)));
         }
@@ -499,6 +586,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
         const double eps = 1.0 / 16777216.0; /* 2^-24 */
         std::vector<BallRec> balls; /* real spheres only, for the bounding-ball tree */
         balls.reserve(d->n_spheres);
+        std::vector<MxBall> mxb(order.size(), MxBall{{0, 0, 0}, 0, false}); /* every sorted slot, for the matrix-pipe operands */
         for (size_t k = 0; k < order.size(); ++k) {
             if (order[k] == 0xFFFFFFFFu) { S[k].x = S[k].y = S[k].z = 0.f; S[k].w = INFINITY; continue; }
             const mirt_sphere& sp = d->spheres[order[k]];
@@ -524,9 +612,11 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
             wf = std::nextafterf(wf, -INFINITY);
             S[k].x = Mf[0]; S[k].y = Mf[1]; S[k].z = Mf[2]; S[k].w = wf;
             balls.push_back(BallRec{{(double)Mf[0], (double)Mf[1], (double)Mf[2]}, rho, (uint32_t)k});
+            mxb[k] = MxBall{{(double)Mf[0], (double)Mf[1], (double)Mf[2]}, rho, true};
         }
         if ((rc = upload(s, S, &s->S))) { mirt_scene_destroy(s); return rc; }
         if ((rc = build_bvh(s, balls, S))) { mirt_scene_destroy(s); return rc; }
+        if ((rc = build_mx(s, mxb))) { mirt_scene_destroy(s); return rc; }
     }
     std::vector<DevStats> st(1);
     memset(st.data(), 0, sizeof(DevStats));
@@ -552,7 +642,7 @@ int mirt_primary_hits_device(const mirt_scene* s, const mirt_camera* cam, const 
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     return o->precision == MIRT_F64 ? launch_primary(s, s->f64, cam, part, d_id, d_t, st)
-                                    : launch_primary(s, s->f32, cam, part, d_id, d_t, st, (o->flags & MIRT_FLAG_BVH) != 0);
+                                    : launch_primary(s, s->f32, cam, part, d_id, d_t, st, (o->flags & MIRT_FLAG_BVH) != 0, use_mx(s, cam, o));
 }
 
 int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, void* d_lin, uint8_t* d_rgb8, void* stream,
@@ -570,8 +660,8 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    rc = o->precision == MIRT_F64 ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st, false)
-                                  : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0);
+    rc = o->precision == MIRT_F64 ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st, false, false)
+                                  : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0, use_mx(s, cam, o));
     if (stats) {
         if (!rc) {
             hipError_t e = hipEventRecord(e1, st);

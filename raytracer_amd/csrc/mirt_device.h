@@ -119,6 +119,10 @@ template <class R> struct DevScene {
     const uint32_t* bvh_idx;
     uint32_t bvh_root; /* a ref like BvhNode::q3.x */
     uint32_t bvh_n_nodes, bvh_n_recs, bvh_depth;
+    /* matrix-pipe broad phase (f32 only, trace_mx): split-f16 sphere operands, 64 x 16 B per tile of 32 sorted spheres,
+     * in the scene's power-of-two scale mx_scale (NULL when the scene does not qualify) */
+    const uint4* SM;
+    float mx_scale;
 };
 template <class R> struct DevCamera { /* struct Camera, camera/camera.rs:107-120, rounded once to Real */
     V3<R> lookfrom, du, dv, ul, px00, disk_u, disk_v;

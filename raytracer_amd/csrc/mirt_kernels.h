@@ -300,12 +300,13 @@ struct F32Lds {
         return res;
     }
 };
-struct GeomLds {
-    const F32Lds& L;
+template <class LDS> struct GeomLdsT {
+    const LDS& L;
     __device__ inline float4 a(uint32_t i) const { return L.A[i]; }
     __device__ inline float4 b(uint32_t i) const { return L.B[i]; }
     __device__ inline uint32_t material(uint32_t i) const { return L.mat[i]; }
 };
+typedef GeomLdsT<F32Lds> GeomLds;
 
 template <bool RES>
 __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t w, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
@@ -419,6 +420,243 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
 #undef MIRT_CONS_QW
 #undef MIRT_CONS_H
 #undef MIRT_CONS_PUSH
+}
+
+/* ---- f32, resident scenes: the broad phase on the matrix pipe -----------------------------------------
+ * The two dot products of the conservative test, h = Dn.M - k1 and e = 2 O.M - k2 - w, are a (rays x K) x (K x spheres)
+ * contraction with a tiny K.  One v_mfma_f32_32x32x16_f16 evaluates it for 32 rays x 32 spheres in 32 cycles - 1 cycle
+ * per (wave, sphere, quantity) where the VALU needs 7-10 - and leaves 2 VALU instructions per pair: q = fma(h, h, e)
+ * and the alignbit that collects its sign.  (The matrix core and the VALU of a SIMD do not run concurrently on gfx950 -
+ * bench/mfma_overlap.hip: the times add - so the gain is the instruction count, 10.3 -> ~5 issue slots per pair.)
+ *
+ * Precision.  f16 operands carry 11 bits, so every f32 value x is split x ~ xh + xl (xh = f16(x), xl = f16(x - xh),
+ * |x - xh - xl| <= max(2^-22 |x|, 2^-25)) and every product uses all four partial products (hh, hl, lh, ll): K = 12
+ * for a 3-vector dot product + 2 + 2 for the split scalars = 16.  f16 x f16 products are exact in the f32 accumulator,
+ * f16 subnormals are honoured, and the accumulation is off by <= 2^-22.8 of the sum of |terms| (bench/mfma_probe.hip,
+ * budgeted here as a = 2^-21).  Everything is evaluated in the scene's power-of-two scale (mx_scale: exact in f32),
+ * chosen so that max(|M|+rho) <= 64: all operands stay far inside the f16 range as long as |O|^2 <= MIRT_MX_K2MAX,
+ * which holds for every ray that starts on a sphere; a ray that violates it (far camera: the host then picks the
+ * VALU kernel anyway; NaN) simply keeps every sphere as a candidate.
+ *   K layout (ray value x sphere value), identical sphere operand for both products:
+ *     k0-3   x: (dh,mh) (dh,ml) (dl,mh) (dl,ml)      k4-7 y likewise      k8-11 z likewise
+ *     k12,13 (-k1h, 1) (-k1l, 1)   |  (-k2h, 1) (-k2l, 1)                 k14,15 (0, wh) (0, wl)  |  (-1, wh) (-1, wl)
+ *   with u = 2^-22, f = 2^-25, everything in scaled units and |Dn| <= 1.0001:
+ *     |dh| <= (2u + 1.01a)(|M| + |O|) + f (2.8 + 1.75 |M|)
+ *     |de| <= (2u + 1.01a)(|O| + |M|)^2 + 1.01 a rho^2 + 1.75 f (2|O| + |M|)        (w and k2 are rounded one-sidedly)
+ *     |dq| <= 2|h| dh + dh^2 + de <= 50.4 eps ((|M|+|O|)^2 + rho^2) + 2^-21.8 (|M| + |O|)   (the fma itself cannot flip a sign)
+ *   Together with the 32 eps of "exact discriminant >= 0 => the line passes the ball" and 40 eps for the f32 ray-side
+ *   constants (trace_cons) this stays below 128 eps ((|M|+|O|)^2 + rho^2) <= 256 eps (|M|^2 + |O|^2 + rho^2), so the
+ *   records carry w = |M|^2 - rho^2 - 256 eps (|M|^2 + rho^2) - 2^-20 (1 + |M|) (rounded down in the split) and the ray
+ *   k2 = |O|^2 (1 - 335 eps) - 2^-19.  -DMIRT_VERIFY_BROAD re-tests every pair exactly here as well.
+ *   Operand lanes: sphere rows come from the A operand (lane l: row l % 32, K half l / 32), rays are the columns (B
+ *   operand, lane l: ray l % 32, K half l / 32), so the wave's 64 rays take two MFMAs per product and each lane
+ *   supplies one K half of its own ray and receives the other lane's half by v_permlane32_swap; a result lane holds
+ *   16 of the 32 rows of one column - rows are ordered so that these are 16 consecutive sorted spheres - and the same
+ *   swap brings the two 16-bit words of a ray together.  The entry lists and the narrow phase are trace_cons's. */
+#define MIRT_MX_K2MAX 36000.0f
+#define MIRT_MX_SHRINK 0.99998f /* <= 1 - 335 * 2^-24 */
+#define MIRT_MX_FLOOR 1.9073486328125e-06f /* 2^-19 */
+typedef _Float16 mirt_h8 __attribute__((ext_vector_type(8)));
+typedef float mirt_f16v __attribute__((ext_vector_type(16)));
+typedef uint32_t mirt_u4 __attribute__((ext_vector_type(4)));
+struct MxLds {
+    uint4 SM[MIRT_LDS_RECORDS * 2]; /* 64 x 16 B per tile of 32 spheres */
+    float4 A[MIRT_LDS_RECORDS];
+    float4 B[MIRT_LDS_RECORDS];
+    uint16_t mat[MIRT_LDS_RECORDS];
+    uint32_t ent[MIRT_F32_WAVES][MIRT_ENT_CAP][MIRT_WAVE];
+    __device__ inline void fill(const DevScene<float>& sc) { /* the host launches this kernel for resident scenes only */
+        const uint32_t ntiles = (sc.n + 31) / 32;
+        for (uint32_t i = threadIdx.x; i < ntiles * 64; i += blockDim.x) SM[i] = sc.SM[i];
+        for (uint32_t i = threadIdx.x; i < sc.n; i += blockDim.x) {
+            A[i] = sc.A[i];
+            B[i] = sc.B[i];
+            mat[i] = (uint16_t)sc.material[i];
+        }
+        __syncthreads();
+    }
+};
+/* The empty asm statements pin ONE conversion per value: without them instruction selection converts the same f32 twice
+ * for the two users of hi - v_fma_mixlo_f16 (the exact product d * inv rounded once) for the residual and
+ * v_cvt_pk_f16_f32 (the f32 product rounded again) for the operand - and the two disagree by one f16 ulp whenever the
+ * f32 value sits on a rounding tie: hi + lo is then off by 2^-11 |x| (found as 2 wrong pixels in 90 000). */
+__device__ inline void mx_split(float x, _Float16& hi, _Float16& lo) {
+    asm volatile("" : "+v"(x));
+    hi = (_Float16)x;
+    asm volatile("" : "+v"(hi));
+    lo = (_Float16)(x - (float)hi);
+    asm volatile("" : "+v"(lo));
+}
+__device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
+                                Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+    best.t = INFINITY;
+    best.idx = 0xFFFFFFFFu;
+    const float a_true = ray_a(ray.d);
+    const uint32_t ntiles = (sc.n + 31) / 32;
+    uint32_t(*ent)[MIRT_WAVE] = L.ent[w];
+    /* ---- the ray's operands ---- */
+    mirt_h8 bgx, bgy, bex, bey;
+    uint32_t amask, omask;
+#ifdef MIRT_VERIFY_BROAD
+    mirt_h8 dbg_op[4];
+#endif
+    {
+        const float inv = 1.0f / sqrtf(a_true);
+        const V3<float> Dn = {ray.d.x * inv, ray.d.y * inv, ray.d.z * inv};
+        const V3<float> O = {ray.o.x * sc.mx_scale, ray.o.y * sc.mx_scale, ray.o.z * sc.mx_scale};
+        const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
+        const float o2 = __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x));
+        const float k2 = o2 * MIRT_MX_SHRINK - MIRT_MX_FLOOR;
+        const bool ok = o2 <= MIRT_MX_K2MAX; /* false for NaN */
+        amask = ok ? 0xFFFFFFFFu : 0xFFFF0000u; /* out of range: every sphere stays a candidate */
+        omask = active ? 0u : 0xFFFFu;          /* no ray: none */
+        _Float16 dhx, dlx, dhy, dly, dhz, dlz, k1h, k1l, ohx, olx, ohy, oly, ohz, olz, k2h, k2l;
+        mx_split(Dn.x, dhx, dlx); mx_split(Dn.y, dhy, dly); mx_split(Dn.z, dhz, dlz); mx_split(-k1, k1h, k1l);
+        mx_split(2.0f * O.x, ohx, olx); mx_split(2.0f * O.y, ohy, oly); mx_split(2.0f * O.z, ohz, olz); mx_split(-k2, k2h, k2l);
+        const _Float16 z = (_Float16)0.0f, m1 = (_Float16)-1.0f;
+        const mirt_h8 glo = {dhx, dhx, dlx, dlx, dhy, dhy, dly, dly}, ghi = {dhz, dhz, dlz, dlz, k1h, k1l, z, z};
+        const mirt_h8 elo = {ohx, ohx, olx, olx, ohy, ohy, oly, oly}, ehi = {ohz, ohz, olz, olz, k2h, k2l, m1, m1};
+        /* X operand: lanes 0-31 their own low half, lanes 32-63 the high half of ray (lane - 32);
+         * Y operand: lanes 0-31 the low half of ray (lane + 32), lanes 32-63 their own high half */
+#ifdef MIRT_VERIFY_BROAD
+        dbg_op[0] = glo; dbg_op[1] = ghi; dbg_op[2] = elo; dbg_op[3] = ehi;
+#endif
+        mirt_u4 gx = __builtin_bit_cast(mirt_u4, glo), gy = __builtin_bit_cast(mirt_u4, ghi);
+        mirt_u4 ex = __builtin_bit_cast(mirt_u4, elo), ey = __builtin_bit_cast(mirt_u4, ehi);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            auto sg = __builtin_amdgcn_permlane32_swap(gx[k], gy[k], false, false);
+            gx[k] = sg[0]; gy[k] = sg[1];
+            auto se = __builtin_amdgcn_permlane32_swap(ex[k], ey[k], false, false);
+            ex[k] = se[0]; ey[k] = se[1];
+        }
+        bgx = __builtin_bit_cast(mirt_h8, gx); bgy = __builtin_bit_cast(mirt_h8, gy);
+        bex = __builtin_bit_cast(mirt_h8, ex); bey = __builtin_bit_cast(mirt_h8, ey);
+    }
+    const mirt_h8* SM = (const mirt_h8*)L.SM;
+    const uint32_t sub = lane >> 5;
+    uint32_t t = 0;
+    while (t < ntiles) { /* one pass unless some lane's entry list fills up */
+        uint32_t cnt = 0;
+        const uint32_t gbase = 2 * t;
+        uint32_t tlimit = t + 0x8000u; /* group numbers in the entries are 16 bit, relative to gbase */
+        tlimit = tlimit < ntiles ? tlimit : ntiles;
+        bool flush = false;
+        for (; t < tlimit && !flush; ++t) {
+            const mirt_h8 a = SM[t * 64 + lane];
+            const mirt_f16v zero = {};
+            uint32_t mx = 2 * t - gbase + sub, my = mx;
+#ifdef MIRT_VERIFY_BROAD
+            float dbg_h[2][16], dbg_e[2][16];
+#endif
+            {
+                const mirt_f16v h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bgx, zero, 0, 0, 0);
+                const mirt_f16v e = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bex, zero, 0, 0, 0);
+#ifdef MIRT_VERIFY_BROAD
+                for (int r = 0; r < 16; ++r) { dbg_h[0][r] = h[r]; dbg_e[0][r] = e[r]; }
+#endif
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = __builtin_amdgcn_alignbit(mx, __float_as_uint(__builtin_fmaf(h[r], h[r], e[r])), 31);
+            }
+            {
+                const mirt_f16v h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bgy, zero, 0, 0, 0);
+                const mirt_f16v e = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bey, zero, 0, 0, 0);
+#ifdef MIRT_VERIFY_BROAD
+                for (int r = 0; r < 16; ++r) { dbg_h[1][r] = h[r]; dbg_e[1][r] = e[r]; }
+#endif
+#pragma unroll
+                for (int r = 0; r < 16; ++r) my = __builtin_amdgcn_alignbit(my, __float_as_uint(__builtin_fmaf(h[r], h[r], e[r])), 31);
+            }
+            /* lanes 0-31 hold (ray l, rows of sub 0) and (ray l + 32, sub 0); lanes 32-63 (ray l - 32, sub 1) and (ray l, sub 1) */
+            auto sw = __builtin_amdgcn_permlane32_swap(mx, my, false, false);
+            mx = (sw[0] & amask) | omask; /* this lane's ray, spheres 32 t .. 32 t + 15 */
+            my = (sw[1] & amask) | omask; /*                  spheres 32 t + 16 .. 32 t + 31 */
+#ifdef MIRT_VERIFY_BROAD
+            for (uint32_t k_ = 0; k_ < 32; ++k_) { /* exact discriminant >= 0 must imply the candidate bit */
+                const uint32_t i_ = t * 32 + k_;
+                if (i_ >= sc.n) break;
+                float4 sa_ = sc.A[i_];
+                V3<float> C_ = {sa_.x, sa_.y, sa_.z};
+                if (i_ >= sc.n_static) {
+                    float4 sb_ = sc.B[i_];
+                    C_ = center_at(C_, V3<float>{sb_.x, sb_.y, sb_.z}, ray.tm);
+                }
+                float hh_, dd_;
+                disc(C_ - ray.o, ray.d, a_true, sa_.w, hh_, dd_);
+                const uint32_t word_ = k_ < 16 ? mx : my;
+                if (active && dd_ >= 0.0f && ((word_ >> (15 - (k_ & 15u))) & 1u)) {
+                    if (atomicAdd(sc.dbg, 1ull) < 8ull) {
+                        const uint32_t sub_ = k_ >> 4, r_ = k_ & 15u, row_ = (r_ & 3u) + 8u * (r_ >> 2) + 4u * sub_;
+                        const mirt_h8 s0_ = SM[t * 64 + row_], s1_ = SM[t * 64 + 32 + row_];
+                        for (int o_ = 0; o_ < 4; ++o_)
+                            printf("[mx op %d lane %u] %a %a %a %a %a %a %a %a\n", o_, lane, (double)dbg_op[o_][0], (double)dbg_op[o_][1], (double)dbg_op[o_][2],
+                                   (double)dbg_op[o_][3], (double)dbg_op[o_][4], (double)dbg_op[o_][5], (double)dbg_op[o_][6], (double)dbg_op[o_][7]);
+                        printf("[mx sph lane %u] %a %a %a %a %a %a %a %a | %a %a %a %a %a %a %a %a\n", lane, (double)s0_[0], (double)s0_[1], (double)s0_[2], (double)s0_[3],
+                               (double)s0_[4], (double)s0_[5], (double)s0_[6], (double)s0_[7], (double)s1_[0], (double)s1_[1], (double)s1_[2], (double)s1_[3],
+                               (double)s1_[4], (double)s1_[5], (double)s1_[6], (double)s1_[7]);
+                    }
+                    if (0)
+                        printf("[mx miss] lane %u tile %u k %u gbase %u cnt %u mx %08x my %08x d %g O %g %g %g D %g %g %g\n", lane, t, k_, gbase, cnt, mx, my, dd_,
+                               ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
+                }
+            }
+            {
+                int missk_ = -1;
+                for (uint32_t k_ = 0; k_ < 32; ++k_) {
+                    const uint32_t i_ = t * 32 + k_;
+                    if (i_ >= sc.n) break;
+                    float4 sa_ = sc.A[i_];
+                    V3<float> C_ = {sa_.x, sa_.y, sa_.z};
+                    if (i_ >= sc.n_static) { float4 sb_ = sc.B[i_]; C_ = center_at(C_, V3<float>{sb_.x, sb_.y, sb_.z}, ray.tm); }
+                    float hh_, dd_;
+                    disc(C_ - ray.o, ray.d, a_true, sa_.w, hh_, dd_);
+                    const uint32_t word_ = k_ < 16 ? mx : my;
+                    if (active && dd_ >= 0.0f && ((word_ >> (15 - (k_ & 15u))) & 1u)) missk_ = (int)k_;
+                }
+                unsigned long long mm_ = __ballot(missk_ >= 0);
+                while (mm_) {
+                    const int L_ = __ffsll((long long)mm_) - 1;
+                    mm_ &= mm_ - 1;
+                    const int kk_ = __shfl(missk_, L_, 64);
+                    const int sub_ = kk_ >> 4, r_ = kk_ & 15, src_ = (L_ & 31) + 32 * sub_, which_ = L_ >> 5;
+                    float hv_ = 0, ev_ = 0;
+                    for (int r = 0; r < 16; ++r)
+                        if (r == r_) { hv_ = dbg_h[which_][r]; ev_ = dbg_e[which_][r]; }
+                    hv_ = __shfl(hv_, src_, 64);
+                    ev_ = __shfl(ev_, src_, 64);
+                    if (lane == 0) printf("[mx raw] ray lane %d k %d: h %.9g e %.9g q %.6g (from lane %d)\n", L_, kk_, hv_, ev_, hv_ * hv_ + ev_, src_);
+                }
+            }
+#endif
+            /* unconditional writes, conditional advance (cnt <= MIRT_ENT_CAP - 2 here: a nearly full list flushes below) */
+            ent[cnt][lane] = mx;
+            cnt += ((mx & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
+            ent[cnt][lane] = my;
+            cnt += ((my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
+            flush = __ballot(cnt > MIRT_ENT_CAP - 2) != 0ull; /* no room for another tile */
+        }
+        pt.stamp(PH_BROAD);
+        /* ---- narrow phase: as in trace_cons ---- */
+        {
+            uint32_t k = 0, m = 0, gi = 0;
+            for (;;) {
+                if (m == 0 && k < cnt) {
+                    const uint32_t e = ent[k][lane];
+                    ++k;
+                    m = ~e & 0xFFFFu;
+                    gi = (gbase + (e >> 16)) * MIRT_CGROUP + (MIRT_CGROUP - 1);
+                }
+                if (__ballot(m != 0) == 0ull) break;
+                if (m != 0) {
+                    const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
+                    m &= m - 1u;
+                    narrow_test(sc, GeomLdsT<MxLds>{L}, gi - bit, ray, a_true, tmin, best);
+                    ++narrow_count;
+                }
+            }
+        }
+        pt.stamp(PH_NARROW);
+    }
 }
 
 /* ---- f32, MIRT_FLAG_BVH: closest hit through the bounding-volume tree --------------------------------
@@ -647,6 +885,19 @@ template <bool RES> struct TracerF32 {
     __device__ inline uint32_t material(uint32_t idx) const { return RES ? (uint32_t)L.mat[idx] : sc.material[idx]; }
 };
 
+struct TracerF32Mx {
+    typedef float Real;
+    static constexpr bool RESUMABLE = false;
+    const DevScene<float>& sc;
+    MxLds& L;
+    uint32_t w;
+    __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
+        trace_mx(sc, L, w, lane, active, ray, tmin, best, nc, pt);
+    }
+    __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const { return make_hit(sc, GeomLdsT<MxLds>{L}, c, ray); }
+    __device__ inline uint32_t material(uint32_t idx) const { return (uint32_t)L.mat[idx]; }
+};
+
 template <class Store, bool DYN> struct TracerF32Bvh {
     typedef float Real;
     static constexpr bool RESUMABLE = DYN; /* render_body may leave a traversal half-way to refill finished lanes */
@@ -866,6 +1117,15 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK) void primary_hits_kernel_f32(DevSce
         TracerF32<false> tr{sc, L, w};
         primary_hits_body(tr, sc, cam, part, wave_global, lane, out_id, out_t);
     }
+}
+
+__global__ __launch_bounds__(MIRT_F32_BLOCK) void primary_hits_kernel_f32_mx(DevScene<float> sc, DevCamera<float> cam, DevPart part, uint32_t* __restrict__ out_id,
+                                                                             float* __restrict__ out_t) {
+    __shared__ MxLds L;
+    L.fill(sc);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    TracerF32Mx tr{sc, L, w};
+    primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_F32_WAVES + w, lane, out_id, out_t);
 }
 
 __global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel_f32_bvh(DevScene<float> sc, DevCamera<float> cam, DevPart part, uint32_t* __restrict__ out_id,
@@ -1106,6 +1366,16 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
         TracerF32<false> tr{sc, L, w};
         render_body(tr, sc, cam, part, rp, partial, stats, lane);
     }
+}
+
+/* the same with the broad phase on the matrix pipe (resident scenes whose coordinates fit the split-f16 operands) */
+__global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32_mx(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
+                                                                       float* __restrict__ partial, DevStats* __restrict__ stats) {
+    __shared__ MxLds L;
+    L.fill(sc);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    TracerF32Mx tr{sc, L, w};
+    render_body(tr, sc, cam, part, rp, partial, stats, lane);
 }
 
 /* ---- K2b (+K3): add the chunks of a pixel in chunk order, scale by 1/spp (camera.rs:246), gamma + quantise
