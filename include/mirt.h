@@ -203,6 +203,11 @@ int mirt_deinterleave_device(const void* d_bands, size_t band_stride_bytes, uint
 /* Rows owned by a part (helper for sizing compact buffers). */
 uint32_t mirt_part_rows(uint32_t height, uint32_t strip_rows, uint32_t part_index, uint32_t part_count);
 
+/* Which closest-hit front end a render / primary-hits call with these arguments runs (no reference counterpart; for
+ * benchmarks and tests): 0 = brute force with the broad phase on the vector ALU, 1 = brute force with the broad phase
+ * on the matrix pipe, 2 = bounding-volume tree, 3 = f64 brute force; negative = MIRT_ERR_* for invalid arguments. */
+int mirt_closest_hit_kind(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts);
+
 /* Counter-based RNG, exposed for known-answer tests: Philox4x32-10 block.  out[4]. */
 void mirt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -116,6 +116,7 @@ EXPORTS = [
     "mirt_quantize_device",
     "mirt_deinterleave_device",
     "mirt_part_rows",
+    "mirt_closest_hit_kind",
     "mirt_philox4x32_10",
 ]
 
@@ -165,6 +166,8 @@ def load():
     lib.mirt_deinterleave_device.argtypes = [vp, sz, u32, u32, u32, u32, u32, vp, vp]
     lib.mirt_part_rows.argtypes = [u32, u32, u32, u32]
     lib.mirt_part_rows.restype = u32
+    lib.mirt_closest_hit_kind.argtypes = [vp, P(MirtCamera), P(MirtOpts)]
+    lib.mirt_closest_hit_kind.restype = C.c_int
     lib.mirt_philox4x32_10.argtypes = [P(u32), P(u32), P(u32)]
     lib.mirt_philox4x32_10.restype = None
     _lib = lib

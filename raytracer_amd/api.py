@@ -424,6 +424,15 @@ class Camera:
         abi.check(abi.load().mirt_primary_hits(ds.handle, C.byref(self.pod), C.byref(o), ids.ctypes.data, t.ctypes.data))
         return ids, t
 
+    def closest_hit_kind(self, scene: Scene, precision=None, accel=None) -> str:
+        """Which closest-hit front end a call with these arguments runs (mirt_closest_hit_kind)."""
+        ds = scene.device_scene(self.device)
+        o = self.opts(precision=self.precision if precision is None else precision, flags=_accel_flags(accel))
+        k = abi.load().mirt_closest_hit_kind(ds.handle, C.byref(self.pod), C.byref(o))
+        if k < 0:
+            abi.check(k)
+        return ("valu", "matrix", "bvh", "f64")[k]
+
     def render(self, scene: Scene, out=None) -> None:
         """Camera::render: PPM P3 on stdout - "P3\\nW H\\n255\\n" then one "r g b\\n" line per pixel
         (camera.rs:233-235,255; rgb.rs:28-36).  A NaN pixel makes the library return MIRT_ERR_NAN

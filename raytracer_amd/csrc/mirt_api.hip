@@ -32,6 +32,7 @@ template <class R> struct SceneBuffers {
     typename Vec4<R>::type *A = nullptr, *B = nullptr;
     DevMaterial<R>* mats = nullptr;
 };
+struct MxBall { double M[3]; double rho; bool real; };
 struct mirt_scene {
     int device = 0;
     uint32_t n = 0, n_static = 0;           /* padded counts (multiples of MIRT_GROUP) seen by the kernels */
@@ -46,9 +47,13 @@ struct mirt_scene {
     uint32_t* bvh_idx = nullptr;
     uint32_t bvh_root = MIRT_BVH_NONE, bvh_n_nodes = 0, bvh_n_recs = 0, bvh_depth = 0;
     bool bvh_ok = false;
-    uint4* SM = nullptr;   /* split-f16 sphere operands of the matrix-pipe broad phase (trace_mx) */
-    float mx_scale = 1.f;  /* power of two: max (|M| + rho) * mx_scale <= 64 */
-    bool mx_ok = false;    /* resident, finite and inside the f16 range */
+    /* matrix-pipe broad phase (trace_mx): the bounding balls on the host, and split-f16 sphere operands on the device for
+     * every power-of-two scale a call has asked for so far (the scale depends on the camera position, see mx_pick) */
+    std::vector<MxBall> mx_balls; /* one per sorted slot; empty when the scene does not qualify */
+    double mx_R = 0;              /* max (|M| + rho) */
+    mutable std::vector<std::pair<int, uint4*>> mx_cache;
+    mutable uint4* SM = nullptr;  /* operands and scale of the call being launched */
+    mutable float mx_scale = 1.f;
     DevStats* stats = nullptr; /* one per scene: calls on one scene handle are not re-entrant */
     std::vector<void*> allocs;
     /* render workspace (per-item partial sums), grown on demand and kept until the scene is destroyed */
@@ -277,29 +282,60 @@ static _Float16 f16_round_down(double x) { /* the largest f16 <= x (finite range
     if ((b & 0x7FFFu) == 0) return f16_from_bits(0x8001u); /* below +-0: the smallest negative subnormal */
     return f16_from_bits((b & 0x8000u) ? (uint16_t)(b + 1) : (uint16_t)(b - 1));
 }
-struct MxBall { double M[3]; double rho; bool real; };
-static int build_mx(mirt_scene* s, const std::vector<MxBall>& balls /* one per sorted slot */) {
-    s->mx_ok = false;
-    if (balls.size() > MIRT_LDS_RECORDS || s->n_materials > 0x10000u) return MIRT_OK;
+/* Does the scene qualify at all?  (resident, finite) */
+static void mx_init(mirt_scene* s, const std::vector<MxBall>& balls /* one per sorted slot */) {
+    s->mx_balls.clear();
+    if (balls.size() > MIRT_LDS_RECORDS || s->n_materials > 0x10000u) return;
     double R = 0;
     for (const MxBall& b : balls)
         if (b.real) {
             const double ext = std::sqrt(b.M[0] * b.M[0] + b.M[1] * b.M[1] + b.M[2] * b.M[2]) + b.rho;
-            if (!(ext < 1e30)) return MIRT_OK; /* NaN / inf / absurd extents: the VALU kernel copes, f16 does not */
+            if (!(ext < 1e30)) return; /* NaN / inf / absurd extents: the VALU kernel copes, f16 does not */
             R = std::max(R, ext);
         }
-    if (!(R < 1e30)) return MIRT_OK; /* NaN / inf / absurd extents: the VALU kernel copes, f16 does not */
+    s->mx_R = R;
+    s->mx_balls = balls;
+}
+/* The scale 2^e of a call: rays start at the lens or on a sphere, so with `reach` = the lens's largest distance from the
+ * origin every ray has |O| <= max(R, reach); the operands fit the f16 range when R 2^e <= 64 and reach 2^e <= 180
+ * (180^2 < MIRT_MX_K2MAX).  The absolute part of the margin (see trace_mx) is fixed in SCALED units, so a camera far
+ * outside the scene, or a scene of tiny spheres around a huge one, makes it large against rho^2: where that is the
+ * case for more than a quarter of the spheres they would be candidates for every ray passing anywhere near them, and
+ * the call stays on the VALU kernel. */
+static bool mx_pick(const mirt_scene* s, const mirt_camera* cam, int* e_out) {
+    if (s->mx_balls.empty() && s->n != 0) return false;
+    auto len = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    const double reach = len(cam->lookfrom) + len(cam->disk_u_r) + len(cam->disk_v_r);
+    if (!(reach < 1e30)) return false;
+    const double need = std::max(s->mx_R, reach * (64.0 / 180.0));
     int e = 0;
-    if (R > 0) {
-        (void)std::frexp(64.0 / R, &e); /* 64 / R = m 2^e, m in [0.5, 1) -> 2^(e-1) <= 64 / R */
+    if (need > 0) {
+        (void)std::frexp(64.0 / need, &e); /* 64 / need = m 2^e, m in [0.5, 1)  ->  2^(e-1) <= 64 / need */
         e -= 1;
     }
-    e = std::max(-100, std::min(100, e));
+    if (e < -100 || e > 100) return false;
     const double sc = std::ldexp(1.0, e);
-    s->mx_scale = (float)sc;
-    const double eps = 1.0 / 16777216.0, F = 1.0 / 1048576.0; /* 2^-24, 2^-20 */
+    size_t real = 0, coarse = 0;
+    for (const MxBall& b : s->mx_balls)
+        if (b.real) {
+            const double Ml = std::sqrt(b.M[0] * b.M[0] + b.M[1] * b.M[1] + b.M[2] * b.M[2]) * sc, rho = b.rho * sc;
+            ++real;
+            if (2.0 * Ml / 2097152.0 + 6.0e-8 > 0.5 * rho * rho) ++coarse;
+        }
+    if (coarse * 4 > real) return false;
+    *e_out = e;
+    return true;
+}
+/* Operands for scale 2^e, built on first use and kept with the scene. */
+static int mx_ensure(const mirt_scene* s, int e) {
+    s->mx_scale = (float)std::ldexp(1.0, e);
+    for (const auto& c : s->mx_cache)
+        if (c.first == e) { s->SM = c.second; return MIRT_OK; }
+    const std::vector<MxBall>& balls = s->mx_balls;
+    const double sc = std::ldexp(1.0, e);
+    const double eps = 1.0 / 16777216.0, F = 1.0 / 2097152.0; /* 2^-24, 2^-21 */
     const size_t ntiles = (balls.size() + 31) / 32;
-    std::vector<uint4> SM(ntiles * 64);
+    std::vector<uint4> SM(std::max<size_t>(ntiles, 1) * 64);
     for (size_t T = 0; T < ntiles; ++T)
         for (uint32_t l = 0; l < 64; ++l) {
             const uint32_t i = l % 32, sub = (i / 4) % 2, r = (i % 4) + 4 * (i / 8);
@@ -316,7 +352,7 @@ static int build_mx(mirt_scene* s, const std::vector<MxBall>& balls /* one per s
                     M2 += m * m;
                 }
                 const double rho = b.rho * sc, Ml = std::sqrt(M2);
-                const double w = M2 - rho * rho - 256.0 * eps * (M2 + rho * rho) - F * (1.0 + Ml);
+                const double w = M2 - rho * rho - 256.0 * eps * (M2 + rho * rho) - F * Ml;
                 wh = (_Float16)w;
                 wl = f16_round_down(w - (double)wh); /* wh + wl <= w */
             }
@@ -326,9 +362,12 @@ static int build_mx(mirt_scene* s, const std::vector<MxBall>& balls /* one per s
             else        { v[0] = mh[2]; v[1] = ml[2]; v[2] = mh[2]; v[3] = ml[2]; v[4] = one;   v[5] = one;   v[6] = wh;    v[7] = wl; }
             memcpy(&SM[T * 64 + l], v, 16);
         }
-    int rc;
-    if ((rc = upload(s, SM, &s->SM))) return rc;
-    s->mx_ok = true;
+    uint4* dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&dev, SM.size() * sizeof(uint4)));
+    const_cast<mirt_scene*>(s)->allocs.push_back(dev);
+    HIP_TRY(hipMemcpy(dev, SM.data(), SM.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    s->mx_cache.emplace_back(e, dev);
+    s->SM = dev;
     return MIRT_OK;
 }
 
@@ -373,16 +412,12 @@ static int check_common(const mirt_scene* s, const mirt_camera* cam, const mirt_
     }
     return MIRT_OK;
 }
-/* The matrix-pipe broad phase serves resident scenes whose rays stay inside the f16 range of the scaled operands: rays
- * start at the lens or on a sphere (|O| <= max(|M| + rho) = 64 scaled), so only the camera position has to be checked.
- * (A ray outside the range is still traced correctly - it keeps every sphere as a candidate - but slowly.) */
-static bool use_mx(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o) {
-    if (o->precision != MIRT_F32 || (o->flags & (MIRT_FLAG_BVH | MIRT_FLAG_VALU_BROAD)) || !s->mx_ok) return false;
-    if (const char* e = getenv("MIRT_BROAD")) /* tuning knob: valu | matrix */
-        if (!strcmp(e, "valu")) return false;
-    auto len = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
-    const double reach = (len(cam->lookfrom) + len(cam->disk_u_r) + len(cam->disk_v_r)) * (double)s->mx_scale;
-    return reach <= 180.0; /* 180^2 < MIRT_MX_K2MAX; false for NaN */
+/* Brute-force f32 calls run their broad phase on the matrix pipe when the scene and the camera allow it (mx_pick). */
+static bool use_mx(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, int* e) {
+    if (o->precision != MIRT_F32 || (o->flags & (MIRT_FLAG_BVH | MIRT_FLAG_VALU_BROAD))) return false;
+    if (const char* v = getenv("MIRT_BROAD")) /* tuning knob: valu | matrix */
+        if (!strcmp(v, "valu")) return false;
+    return mx_pick(s, cam, e);
 }
 static uint32_t grid_for(uint32_t W, uint32_t local_rows, uint32_t waves_per_block) {
     uint32_t tiles = ((W + 7) / 8) * ((local_rows + 7) / 8);
@@ -510,6 +545,14 @@ int mirt_device_count(void) {
 uint32_t mirt_part_rows(uint32_t height, uint32_t strip_rows, uint32_t part_index, uint32_t part_count) {
     return part_rows(height, strip_rows ? strip_rows : 8u, part_index, part_count);
 }
+int mirt_closest_hit_kind(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o) {
+    int rc = check_common(s, cam, o);
+    if (rc) return rc;
+    if (o->precision == MIRT_F64) return 3;
+    if (o->flags & MIRT_FLAG_BVH) return 2;
+    int e = 0;
+    return use_mx(s, cam, o, &e) ? 1 : 0;
+}
 void mirt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }
@@ -616,7 +659,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
         }
         if ((rc = upload(s, S, &s->S))) { mirt_scene_destroy(s); return rc; }
         if ((rc = build_bvh(s, balls, S))) { mirt_scene_destroy(s); return rc; }
-        if ((rc = build_mx(s, mxb))) { mirt_scene_destroy(s); return rc; }
+        mx_init(s, mxb);
     }
     std::vector<DevStats> st(1);
     memset(st.data(), 0, sizeof(DevStats));
@@ -641,8 +684,11 @@ int mirt_primary_hits_device(const mirt_scene* s, const mirt_camera* cam, const 
     if ((rc = make_part(cam, o, &part))) return rc;
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
+    int mx_e = 0;
+    const bool mx = use_mx(s, cam, o, &mx_e);
+    if (mx && (rc = mx_ensure(s, mx_e))) return rc;
     return o->precision == MIRT_F64 ? launch_primary(s, s->f64, cam, part, d_id, d_t, st)
-                                    : launch_primary(s, s->f32, cam, part, d_id, d_t, st, (o->flags & MIRT_FLAG_BVH) != 0, use_mx(s, cam, o));
+                                    : launch_primary(s, s->f32, cam, part, d_id, d_t, st, (o->flags & MIRT_FLAG_BVH) != 0, mx);
 }
 
 int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, void* d_lin, uint8_t* d_rgb8, void* stream,
@@ -654,6 +700,9 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    int mx_e = 0;
+    const bool mx = use_mx(s, cam, o, &mx_e);
+    if (mx && (rc = mx_ensure(s, mx_e))) return rc; /* before the timed region: the first call at a new scale uploads operands */
     HIP_TRY(hipMemsetAsync(s->stats, 0, sizeof(DevStats), st)); /* counters and the work-queue head */
     if (stats) {
         HIP_TRY(hipEventCreate(&e0));
@@ -661,7 +710,7 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
         HIP_TRY(hipEventRecord(e0, st));
     }
     rc = o->precision == MIRT_F64 ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st, false, false)
-                                  : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0, use_mx(s, cam, o));
+                                  : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0, mx);
     if (stats) {
         if (!rc) {
             hipError_t e = hipEventRecord(e1, st);

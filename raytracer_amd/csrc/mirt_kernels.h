@@ -440,14 +440,18 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
  *   K layout (ray value x sphere value), identical sphere operand for both products:
  *     k0-3   x: (dh,mh) (dh,ml) (dl,mh) (dl,ml)      k4-7 y likewise      k8-11 z likewise
  *     k12,13 (-k1h, 1) (-k1l, 1)   |  (-k2h, 1) (-k2l, 1)                 k14,15 (0, wh) (0, wl)  |  (-1, wh) (-1, wl)
- *   with u = 2^-22, f = 2^-25, everything in scaled units and |Dn| <= 1.0001:
+ *   with u = 2^-22, f = 2^-25 (half the f16 subnormal spacing), everything in scaled units and |Dn| <= 1.0001:
  *     |dh| <= (2u + 1.01a)(|M| + |O|) + f (2.8 + 1.75 |M|)
  *     |de| <= (2u + 1.01a)(|O| + |M|)^2 + 1.01 a rho^2 + 1.75 f (2|O| + |M|)        (w and k2 are rounded one-sidedly)
- *     |dq| <= 2|h| dh + dh^2 + de <= 50.4 eps ((|M|+|O|)^2 + rho^2) + 2^-21.8 (|M| + |O|)   (the fma itself cannot flip a sign)
+ *     |dq| <= 2|h| dh + dh^2 + de <= 50.4 eps ((|M|+|O|)^2 + rho^2) + f (7.35 |M| + 9.1 |O|)   (the fma itself cannot flip a sign)
  *   Together with the 32 eps of "exact discriminant >= 0 => the line passes the ball" and 40 eps for the f32 ray-side
- *   constants (trace_cons) this stays below 128 eps ((|M|+|O|)^2 + rho^2) <= 256 eps (|M|^2 + |O|^2 + rho^2), so the
- *   records carry w = |M|^2 - rho^2 - 256 eps (|M|^2 + rho^2) - 2^-20 (1 + |M|) (rounded down in the split) and the ray
- *   k2 = |O|^2 (1 - 335 eps) - 2^-19.  -DMIRT_VERIFY_BROAD re-tests every pair exactly here as well.
+ *   constants (trace_cons) the relative part stays below 128 eps ((|M|+|O|)^2 + rho^2) <= 256 eps (|M|^2 + |O|^2 + rho^2);
+ *   the absolute part (9.1 f < 2^-21) is linear in |M| and |O|.  So the records carry
+ *   w = |M|^2 - rho^2 - 256 eps (|M|^2 + rho^2) - 2^-21 |M| (rounded down in the split) and the ray
+ *   k2 = |O|^2 (1 - 335 eps) - 2^-20.9 |O| - 2^-24 (the last term covers the split of k2 itself).  The absolute part is
+ *   what limits the dynamic range: where it is not small against rho^2 for most spheres (radius-0.01 spheres on a
+ *   radius-1e5 ground) the host keeps the scene on the VALU kernel.  -DMIRT_VERIFY_BROAD re-tests every pair exactly
+ *   here as well.
  *   Operand lanes: sphere rows come from the A operand (lane l: row l % 32, K half l / 32), rays are the columns (B
  *   operand, lane l: ray l % 32, K half l / 32), so the wave's 64 rays take two MFMAs per product and each lane
  *   supplies one K half of its own ray and receives the other lane's half by v_permlane32_swap; a result lane holds
@@ -455,7 +459,8 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
  *   swap brings the two 16-bit words of a ray together.  The entry lists and the narrow phase are trace_cons's. */
 #define MIRT_MX_K2MAX 36000.0f
 #define MIRT_MX_SHRINK 0.99998f /* <= 1 - 335 * 2^-24 */
-#define MIRT_MX_FLOOR 1.9073486328125e-06f /* 2^-19 */
+#define MIRT_MX_FLOOR_LIN 5.2e-7f /* >= 2^-20.9 */
+#define MIRT_MX_FLOOR_ABS 6.0e-8f /* >= 2^-24 */
 typedef _Float16 mirt_h8 __attribute__((ext_vector_type(8)));
 typedef float mirt_f16v __attribute__((ext_vector_type(16)));
 typedef uint32_t mirt_u4 __attribute__((ext_vector_type(4)));
@@ -497,16 +502,13 @@ __device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w,
     /* ---- the ray's operands ---- */
     mirt_h8 bgx, bgy, bex, bey;
     uint32_t amask, omask;
-#ifdef MIRT_VERIFY_BROAD
-    mirt_h8 dbg_op[4];
-#endif
     {
         const float inv = 1.0f / sqrtf(a_true);
         const V3<float> Dn = {ray.d.x * inv, ray.d.y * inv, ray.d.z * inv};
         const V3<float> O = {ray.o.x * sc.mx_scale, ray.o.y * sc.mx_scale, ray.o.z * sc.mx_scale};
         const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
         const float o2 = __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x));
-        const float k2 = o2 * MIRT_MX_SHRINK - MIRT_MX_FLOOR;
+        const float k2 = o2 * MIRT_MX_SHRINK - __builtin_fmaf(MIRT_MX_FLOOR_LIN, sqrtf(o2), MIRT_MX_FLOOR_ABS);
         const bool ok = o2 <= MIRT_MX_K2MAX; /* false for NaN */
         amask = ok ? 0xFFFFFFFFu : 0xFFFF0000u; /* out of range: every sphere stays a candidate */
         omask = active ? 0u : 0xFFFFu;          /* no ray: none */
@@ -518,9 +520,6 @@ __device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w,
         const mirt_h8 elo = {ohx, ohx, olx, olx, ohy, ohy, oly, oly}, ehi = {ohz, ohz, olz, olz, k2h, k2l, m1, m1};
         /* X operand: lanes 0-31 their own low half, lanes 32-63 the high half of ray (lane - 32);
          * Y operand: lanes 0-31 the low half of ray (lane + 32), lanes 32-63 their own high half */
-#ifdef MIRT_VERIFY_BROAD
-        dbg_op[0] = glo; dbg_op[1] = ghi; dbg_op[2] = elo; dbg_op[3] = ehi;
-#endif
         mirt_u4 gx = __builtin_bit_cast(mirt_u4, glo), gy = __builtin_bit_cast(mirt_u4, ghi);
         mirt_u4 ex = __builtin_bit_cast(mirt_u4, elo), ey = __builtin_bit_cast(mirt_u4, ehi);
 #pragma unroll
@@ -546,24 +545,15 @@ __device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w,
             const mirt_h8 a = SM[t * 64 + lane];
             const mirt_f16v zero = {};
             uint32_t mx = 2 * t - gbase + sub, my = mx;
-#ifdef MIRT_VERIFY_BROAD
-            float dbg_h[2][16], dbg_e[2][16];
-#endif
             {
                 const mirt_f16v h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bgx, zero, 0, 0, 0);
                 const mirt_f16v e = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bex, zero, 0, 0, 0);
-#ifdef MIRT_VERIFY_BROAD
-                for (int r = 0; r < 16; ++r) { dbg_h[0][r] = h[r]; dbg_e[0][r] = e[r]; }
-#endif
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = __builtin_amdgcn_alignbit(mx, __float_as_uint(__builtin_fmaf(h[r], h[r], e[r])), 31);
             }
             {
                 const mirt_f16v h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bgy, zero, 0, 0, 0);
                 const mirt_f16v e = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bey, zero, 0, 0, 0);
-#ifdef MIRT_VERIFY_BROAD
-                for (int r = 0; r < 16; ++r) { dbg_h[1][r] = h[r]; dbg_e[1][r] = e[r]; }
-#endif
 #pragma unroll
                 for (int r = 0; r < 16; ++r) my = __builtin_amdgcn_alignbit(my, __float_as_uint(__builtin_fmaf(h[r], h[r], e[r])), 31);
             }
@@ -584,48 +574,7 @@ __device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w,
                 float hh_, dd_;
                 disc(C_ - ray.o, ray.d, a_true, sa_.w, hh_, dd_);
                 const uint32_t word_ = k_ < 16 ? mx : my;
-                if (active && dd_ >= 0.0f && ((word_ >> (15 - (k_ & 15u))) & 1u)) {
-                    if (atomicAdd(sc.dbg, 1ull) < 8ull) {
-                        const uint32_t sub_ = k_ >> 4, r_ = k_ & 15u, row_ = (r_ & 3u) + 8u * (r_ >> 2) + 4u * sub_;
-                        const mirt_h8 s0_ = SM[t * 64 + row_], s1_ = SM[t * 64 + 32 + row_];
-                        for (int o_ = 0; o_ < 4; ++o_)
-                            printf("[mx op %d lane %u] %a %a %a %a %a %a %a %a\n", o_, lane, (double)dbg_op[o_][0], (double)dbg_op[o_][1], (double)dbg_op[o_][2],
-                                   (double)dbg_op[o_][3], (double)dbg_op[o_][4], (double)dbg_op[o_][5], (double)dbg_op[o_][6], (double)dbg_op[o_][7]);
-                        printf("[mx sph lane %u] %a %a %a %a %a %a %a %a | %a %a %a %a %a %a %a %a\n", lane, (double)s0_[0], (double)s0_[1], (double)s0_[2], (double)s0_[3],
-                               (double)s0_[4], (double)s0_[5], (double)s0_[6], (double)s0_[7], (double)s1_[0], (double)s1_[1], (double)s1_[2], (double)s1_[3],
-                               (double)s1_[4], (double)s1_[5], (double)s1_[6], (double)s1_[7]);
-                    }
-                    if (0)
-                        printf("[mx miss] lane %u tile %u k %u gbase %u cnt %u mx %08x my %08x d %g O %g %g %g D %g %g %g\n", lane, t, k_, gbase, cnt, mx, my, dd_,
-                               ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
-                }
-            }
-            {
-                int missk_ = -1;
-                for (uint32_t k_ = 0; k_ < 32; ++k_) {
-                    const uint32_t i_ = t * 32 + k_;
-                    if (i_ >= sc.n) break;
-                    float4 sa_ = sc.A[i_];
-                    V3<float> C_ = {sa_.x, sa_.y, sa_.z};
-                    if (i_ >= sc.n_static) { float4 sb_ = sc.B[i_]; C_ = center_at(C_, V3<float>{sb_.x, sb_.y, sb_.z}, ray.tm); }
-                    float hh_, dd_;
-                    disc(C_ - ray.o, ray.d, a_true, sa_.w, hh_, dd_);
-                    const uint32_t word_ = k_ < 16 ? mx : my;
-                    if (active && dd_ >= 0.0f && ((word_ >> (15 - (k_ & 15u))) & 1u)) missk_ = (int)k_;
-                }
-                unsigned long long mm_ = __ballot(missk_ >= 0);
-                while (mm_) {
-                    const int L_ = __ffsll((long long)mm_) - 1;
-                    mm_ &= mm_ - 1;
-                    const int kk_ = __shfl(missk_, L_, 64);
-                    const int sub_ = kk_ >> 4, r_ = kk_ & 15, src_ = (L_ & 31) + 32 * sub_, which_ = L_ >> 5;
-                    float hv_ = 0, ev_ = 0;
-                    for (int r = 0; r < 16; ++r)
-                        if (r == r_) { hv_ = dbg_h[which_][r]; ev_ = dbg_e[which_][r]; }
-                    hv_ = __shfl(hv_, src_, 64);
-                    ev_ = __shfl(ev_, src_, 64);
-                    if (lane == 0) printf("[mx raw] ray lane %d k %d: h %.9g e %.9g q %.6g (from lane %d)\n", L_, kk_, hv_, ev_, hv_ * hv_ + ev_, src_);
-                }
+                if (active && dd_ >= 0.0f && ((word_ >> (15 - (k_ & 15u))) & 1u)) atomicAdd(sc.dbg, 1ull);
             }
 #endif
             /* unconditional writes, conditional advance (cnt <= MIRT_ENT_CAP - 2 here: a nearly full list flushes below) */

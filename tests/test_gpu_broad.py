@@ -1,0 +1,175 @@
+"""The two broad phases of the f32 brute-force kernel - vector ALU (MIRT_FLAG_VALU_BROAD) and matrix pipe (the default
+for resident scenes inside the f16 range, split-f16 operands through v_mfma_f32_32x32x16_f16) - must select supersets of
+the exact candidates, i.e. give the same (id, t) for every ray: maps bit-exact against the f32 oracle and against each
+other, rendered images bit-identical, and the host must fall back to the vector ALU where the operands would not fit."""
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, presets
+from raytracer_amd.api import Camera, Dielectric, Lambertian, Metal, Scene, Sphere
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return a.view(np.uint32)
+
+
+def _maps(oracle, sc, cam, expect="matrix", check_oracle=True):
+    assert cam.closest_hit_kind(sc, precision=abi.F32) == expect
+    assert cam.closest_hit_kind(sc, precision=abi.F32, accel="valu") == "valu"
+    ids, t = cam.primary_hits(sc, precision=abi.F32)
+    v_ids, v_t = cam.primary_hits(sc, precision=abi.F32, accel="valu")
+    assert np.array_equal(ids, v_ids) and np.array_equal(bits(t), bits(v_t))
+    if check_oracle:
+        o_ids, o_t = oracle.primary_hits(sc.flat, cam.pod, abi.F32)
+        assert np.array_equal(ids, o_ids) and np.array_equal(bits(t), bits(o_t))
+    return ids
+
+
+@pytest.mark.parametrize("width", [64, 400, 1920])
+def test_matrix_and_valu_maps_bouncing_balls(oracle, width):
+    """400 wide holds the two pixels that exposed a double f32 -> f16 conversion (rounding ties) in the first version."""
+    ids = _maps(oracle, presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(width, 0, 50), check_oracle=width <= 400)
+    assert (ids != abi.MISS_ID).any() and (ids == abi.MISS_ID).any()
+
+
+def test_matrix_maps_presets(oracle):
+    _maps(oracle, presets.mars_texture_scene(), presets.default_camera(400, 0, 50))
+    _maps(oracle, presets.scene(), presets.plain_camera(320, 0, 10))
+    _maps(oracle, presets.blur_scene(), presets.plain_camera(320, 0, 10))
+
+
+@pytest.mark.parametrize("n,seed", [(31, 1), (32, 2), (33, 3), (500, 4), (1000, 5), (1024, 6)])
+def test_matrix_maps_random_scenes(oracle, n, seed):
+    """Tile boundaries (31 / 32 / 33 spheres) and the largest resident scene (1024)."""
+    sc = presets.stress_scene(n, seed=seed)
+    cam = presets.stress_camera(160, 0, 50)
+    ids = _maps(oracle, sc, cam)
+    assert len(np.unique(ids)) > min(n, 100) // 8
+
+
+def test_larger_scenes_stay_on_the_valu_kernel(oracle):
+    sc = presets.stress_scene(1100, seed=7)
+    cam = presets.stress_camera(96, 0, 50)
+    _maps(oracle, sc, cam, expect="valu")
+
+
+def _moving_mix(scale, n=300, seed=9):
+    rng = np.random.default_rng(seed)
+    sc = Scene()
+    mats = [Lambertian.new((0.5, 0.5, 0.5), 1.0), Metal.new((0.8, 0.8, 0.8), 0.1), Dielectric.new(1.5)]
+    sc.add(Sphere.new_static(1000.0 * scale, (0.0, -1000.0 * scale, 0.0), mats[0]))
+    for k in range(n):
+        c = rng.uniform(-8, 8, 3) * scale
+        c[1] = abs(c[1]) * 0.3 + 0.2 * scale
+        r = float(rng.uniform(0.05, 0.4)) * scale
+        if k % 3 == 0:
+            c1 = c + rng.uniform(-0.5, 0.5, 3) * scale
+            sc.add(Sphere.new(r, tuple(c), tuple(c1), mats[k % 3]))
+        else:
+            sc.add(Sphere.new_static(r, tuple(c), mats[k % 3]))
+    sc.build_bvh()
+    cam = Camera.build((13.0 * scale, 2.0 * scale, 3.0 * scale), (0.0, 0.0, 0.0), None, 240, 16.0 / 9.0, 0, 0.35, None, None, 10)
+    return sc, cam
+
+
+@pytest.mark.parametrize("scale", [1.0, 2.0 ** -10, 1e-3, 1e3, 3e4])
+def test_matrix_maps_are_scale_free(oracle, scale):
+    """The operands live in the scene's own power-of-two scale: tiny and huge scenes behave like the unit-sized one."""
+    sc, cam = _moving_mix(scale)
+    ids = _maps(oracle, sc, cam)
+    assert len(np.unique(ids)) > 50
+
+
+@pytest.mark.parametrize("ground,r,expect", [(1e3, 0.02, "matrix"), (1e5, 0.01, "valu")])
+def test_small_spheres_next_to_a_huge_one(oracle, ground, r, expect):
+    """Dynamic range: the absolute part of the split-f16 margin (f16 subnormal spacing in the scene scale) against r^2.
+    Radius 0.02 on a radius-1e3 ground still runs on the matrix pipe; radius 0.01 on a radius-1e5 ground would make every
+    sphere a candidate for every nearby ray, so the host keeps that scene on the vector ALU."""
+    rng = np.random.default_rng(5)
+    sc = Scene()
+    m = Lambertian.new((0.5, 0.5, 0.5), 1.0)
+    sc.add(Sphere.new_static(ground, (0.0, -ground, 0.0), m))
+    for k in range(400):
+        c = rng.uniform(-1, 1, 3)
+        sc.add(Sphere.new_static(r, (float(c[0]), r, float(c[2])), m))
+    sc.build_bvh()
+    cam = Camera.build((2.0, 0.6, 1.0), (0.0, 0.0, 0.0), None, 400, 1.5, 0, 0.9, None, None, 10)
+    ids = _maps(oracle, sc, cam, expect=expect)
+    assert len(np.unique(ids)) > 200
+
+
+def test_far_cameras_rescale_and_very_far_ones_fall_back(oracle):
+    """Rays start on spheres or at the lens, so the operand scale follows the camera position: a camera several scene
+    radii away still runs on the matrix pipe (coarser scale), one so far away that the absolute part of the margin
+    swamps r^2 for most spheres stays on the vector ALU."""
+    rng = np.random.default_rng(2)
+    sc = Scene()
+    m = Metal.new((0.8, 0.8, 0.8), None)
+    for k in range(200):
+        c = rng.uniform(-30, 30, 3)
+        sc.add(Sphere.new_static(float(rng.uniform(0.5, 2.0)), tuple(c), m))
+    sc.build_bvh()
+    near = Camera.build((150.0, 40.0, 30.0), (0.0, 0.0, 0.0), None, 200, 1.0, 0, 0.5, None, None, 5)
+    far = Camera.build((4000.0, 400.0, 300.0), (0.0, 0.0, 0.0), None, 200, 1.0, 0, 0.02, 4030.0, None, 5)
+    very_far = Camera.build((4.0e5, 4.0e4, 3.0e4), (0.0, 0.0, 0.0), None, 200, 1.0, 0, 2.5e-4, 4.03e5, None, 5)
+    assert len(np.unique(_maps(oracle, sc, near, expect="matrix"))) > 50
+    assert len(np.unique(_maps(oracle, sc, far, expect="matrix"))) > 50
+    assert len(np.unique(_maps(oracle, sc, very_far, expect="valu"))) > 5
+
+
+def test_off_origin_cluster_of_small_spheres_falls_back(oracle):
+    """Small spheres far from the coordinate origin: the absolute part of the margin grows with |M| (f16 subnormal lo parts)
+    and would exceed r^2 here, so the host keeps the scene on the vector ALU; ten times larger spheres use the matrix pipe."""
+    rng = np.random.default_rng(11)
+    sc = Scene()
+    for k in range(200):
+        c = rng.uniform(-3, 3, 3) + np.array([500.0, 20.0, -300.0])
+        sc.add(Sphere.new_static(float(rng.uniform(0.02, 0.1)), tuple(c), Metal.new((0.8, 0.8, 0.8), None)))
+    sc.build_bvh()
+    cam = Camera.build((480.0, 25.0, -290.0), (500.0, 20.0, -300.0), None, 200, 1.0, 0, 0.35, None, None, 5)
+    ids = _maps(oracle, sc, cam, expect="valu")
+    assert len(np.unique(ids)) > 50
+    sc = Scene()
+    for k in range(200):
+        c = rng.uniform(-30, 30, 3) + np.array([500.0, 20.0, -300.0])
+        sc.add(Sphere.new_static(float(rng.uniform(0.5, 1.0)), tuple(c), Metal.new((0.8, 0.8, 0.8), None)))
+    sc.build_bvh()
+    cam = Camera.build((400.0, 45.0, -250.0), (500.0, 20.0, -300.0), None, 200, 1.0, 0, 0.5, None, None, 5)
+    ids = _maps(oracle, sc, cam, expect="matrix")
+    assert len(np.unique(ids)) > 50
+
+
+@pytest.mark.parametrize("name", ["balls", "mars", "mix"])
+def test_render_is_bit_identical_on_both_broad_phases(name):
+    if name == "balls":
+        sc, cam = presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(160, 8, 50)
+    elif name == "mars":
+        sc, cam = presets.mars_texture_scene(), presets.default_camera(160, 8, 20)
+    else:
+        sc, cam = _moving_mix(1.0)
+        cam = Camera.build((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), None, 128, 16.0 / 9.0, 6, 0.35, 10.0, 0.02, 30)
+    assert cam.closest_hit_kind(sc, precision=abi.F32) == "matrix"
+    a, a8 = cam.render_arrays(sc, precision=abi.F32, seed=4)
+    st_a = dict(cam.last_stats)
+    b, b8 = cam.render_arrays(sc, precision=abi.F32, seed=4, accel="valu")
+    st_b = dict(cam.last_stats)
+    assert np.array_equal(bits(a), bits(b)) and np.array_equal(a8, b8)
+    assert st_a["segments"] == st_b["segments"] and st_a["sphere_tests"] == st_b["sphere_tests"]
+    # the matrix pipe's margins are a little wider: a few more candidates, never fewer hits
+    assert st_a["narrow_tests"] <= 1.1 * st_b["narrow_tests"] + 64
+
+
+def test_inside_a_sphere_and_degenerate_inputs(oracle):
+    sc = Scene()
+    m = Dielectric.new(1.5)
+    sc.add(Sphere.new_static(5.0, (0.0, 0.0, 0.0), m))       # camera inside
+    sc.add(Sphere.new_static(0.0, (0.0, 0.0, -2.0), m))      # zero radius
+    sc.add(Sphere.new_static(-1.0, (1.0, 0.0, -2.0), m))     # negative radius clamps to zero (sphere.rs:31)
+    sc.add(Sphere.new(0.3, (-1.0, 0.0, -2.0), (-1.0, 0.0, -2.0), m))  # "moving" without travel
+    for k in range(6):  # (degenerate spheres count as "too small for the f16 margins": keep them a minority)
+        sc.add(Sphere.new_static(0.2, (-1.5 + 0.6 * k, 1.0, -3.0), m))
+    sc.build_bvh()
+    ids = _maps(oracle, sc, Camera.build((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), None, 96, 1.0, 0, None, None, None, 10))
+    assert 0 in ids and 3 in ids

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU tests, then the bench with the matrix-pipe and the VALU broad phase, then the -DMIRT_VERIFY_BROAD build (variants/verify.so)
-timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/t_mx.log 2>&1
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/t_mx.log 2>&1
 rc=$?; echo "pytest rc=$rc"; tail -5 gpurun_out/t_mx.log
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 120 python bench.py --steps 6 --warmup 1 --no-cpu-baseline > gpurun_out/b_mx.log 2>&1 || { tail -5 gpurun_out/b_mx.log; exit 1; }
