@@ -85,7 +85,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--accel", default="brute", choices=["brute", "bvh"], help="closest-hit method: the brute-force tile loop (the metric) or the bounding-ball tree")
+    ap.add_argument("--accel", default="brute", choices=["brute", "valu", "bvh"],
+                    help="closest-hit method: brute = the brute-force tile loop (the metric; broad phase on the matrix pipe where the scene allows it), "
+                         "valu = the same loop with the broad phase kept on the vector ALU, bvh = the bounding-ball tree")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra launches (valu_broad, accel_bvh): profiling runs want one kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets N ranks rehearse the N>1 path on ONE GPU")
     args = ap.parse_args()
 
@@ -121,7 +124,9 @@ def main():
     band8 = torch.zeros((rows0, W, 3), dtype=torch.uint8, device="cuda")
     frame = torch.zeros((H, W, 3), dtype=real, device="cuda") if rank == 0 else None
     opts = cam.opts(precision=args.precision, seed=args.seed, strip_rows=S, part_index=rank, part_count=world,
-                    flags=abi.FLAG_COMPACT_ROWS | (abi.FLAG_BVH if args.accel == "bvh" else 0))
+                    flags=abi.FLAG_COMPACT_ROWS | {"brute": 0, "valu": abi.FLAG_VALU_BROAD, "bvh": abi.FLAG_BVH}[args.accel])
+    kind = lib.mirt_closest_hit_kind(ds.handle, C.byref(cam.pod), C.byref(opts))  # 0 valu, 1 matrix pipe, 2 tree, 3 f64
+    abi.check(min(kind, 0))
     stream = torch.cuda.current_stream().cuda_stream
     elem = 3 * (4 if args.precision == 32 else 8)
 
@@ -183,7 +188,9 @@ def main():
                 "workload": f"{scene_name}: {scene.flat.n_spheres} spheres, {W}x{H}, {cam.pod.samples_per_pixel} spp, depth {cam.pod.max_bounce_depth}",
                 "parallelism": f"interleaved {S}-row strips over {world} GPU(s), RCCL all-gather of f32 RGB bands",
                 "seed": args.seed,
-                "closest_hit": "brute-force LDS tile loop" if args.accel == "brute" else "bounding-ball tree (MIRT_FLAG_BVH)",
+                "closest_hit": ["brute-force LDS tile loop, broad phase on the vector ALU",
+                                "brute-force LDS tile loop, broad-phase dot products on the matrix pipe (split-f16 MFMA), exact narrow phase on the vector ALU",
+                                "bounding-ball tree (MIRT_FLAG_BVH)", "brute-force tile loop, f64"][kind],
             },
             "roofline": {
                 "bound": "valu_fp32",
@@ -193,11 +200,13 @@ def main():
                 "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
                 # HBM bytes per launch of this kernel, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE in separate passes
                 # (profiles/r01_v5_hbm_traffic.txt; not re-measured by this script).  Only quoted for the workload it was taken on.
-                "traffic": 8.3e8 if (args.workload == "balls1080p" and (W, cam.pod.samples_per_pixel, args.precision, args.accel, world) == (1920, 64, 32, "brute", 1)) else None,
-                "kernel": ("render_kernel_f32" if args.accel == "brute" else "render_kernel_f32_bvh") if args.precision == 32 else "render_kernel_f64<2>",
+                "traffic": 8.3e8 if (args.workload == "balls1080p" and (W, cam.pod.samples_per_pixel, world) == (1920, 64, 1) and kind in (0, 1)) else None,
+                "kernel": ["render_kernel_f32", "render_kernel_f32_mx", "render_kernel_f32_bvh(_lds)", "render_kernel_f64<2>"][kind],
                 "kernel_ms_avg": round(kern_ms / max(1, len(stats)), 3),
                 "flops_per_segment": round(flops / max(seg, 1), 1),
-                "note": "algorithmic flops = 18/static sphere test + 27/moving sphere test + 5/segment (SURVEY.md 8d); rank 0's launches",
+                "note": "algorithmic flops = 18/static sphere test + 27/moving sphere test + 5/segment (SURVEY.md 8d); rank 0's launches"
+                        + ("; every (ray, sphere) pair is still tested, but the two dot products of the broad phase run on the matrix pipe, so the "
+                           "algorithmic rate can exceed the vector-ALU peak it is priced against (DESIGN.md 5c; `valu_broad` below is the all-VALU kernel)" if kind == 1 else ""),
             },
             "diagnostics": {
                 "segments_per_step": seg_all / args.steps,
@@ -205,7 +214,19 @@ def main():
                 "narrow_tests_per_segment": round(narrow_all / max(seg_all, 1.0), 3),
             },
         }
-        if world == 1 and args.accel == "brute" and args.precision == 32:
+        if world == 1 and kind == 1 and not args.no_extras:
+            # the same frame with the broad phase on the vector ALU (MIRT_FLAG_VALU_BROAD): the kernel the VALU roofline describes directly
+            o3 = cam.opts(precision=32, seed=args.seed, strip_rows=S, part_index=0, part_count=1, flags=abi.FLAG_COMPACT_ROWS | abi.FLAG_VALU_BROAD)
+            st3 = abi.MirtStats()
+            ms3 = []
+            for _ in range(3):
+                abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(o3), band.data_ptr(), band8.data_ptr(), stream, C.byref(st3)))
+                ms3.append(st3.kernel_ms)
+            fl3 = 18 * st3.static_tests + 27 * st3.moving_tests + 5 * st3.segments
+            out["valu_broad"] = {"value": round(st3.segments / (min(ms3) * 1e-3) / 1e6, 3), "unit": "Mrays/s", "kernel": "render_kernel_f32", "kernel_ms": round(min(ms3), 3),
+                                 "frac": round(fl3 / (min(ms3) * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4),
+                                 "note": "same frame, same image, broad phase on the vector ALU: fraction of the FP32 VALU peak in the same algorithmic flops"}
+        if world == 1 and args.accel == "brute" and args.precision == 32 and not args.no_extras:
             # not the metric: the same frame through the bounding-volume tree (MIRT_FLAG_BVH), bit-identical image
             o2 = cam.opts(precision=32, seed=args.seed, strip_rows=S, part_index=0, part_count=1, flags=abi.FLAG_COMPACT_ROWS | abi.FLAG_BVH)
             st2 = abi.MirtStats()

@@ -6,11 +6,11 @@ BARGS="$*"
 root=$GRAFT_REPO_ROOT; [ -z "$root" ] && root=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $root
 out=gpurun_out/prof_$tag; mkdir -p $out
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o k -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline $BARGS > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o k -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras $BARGS > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
 cp $out/kt/k_kernel_stats.csv $out/kernel_stats.csv 2>/dev/null || find $out/kt -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 tools/pmc.sh $tag $BARGS > $out/sq_pmc.txt 2>&1 || { tail -5 $out/sq_pmc.txt; exit 1; }
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 180 rocprofv3 --pmc $c --output-format csv -d $out/hbm_$c -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $BARGS > $out/hbm_$c.log 2>&1 || { tail -5 $out/hbm_$c.log; exit 1; }
+  timeout -s KILL 180 rocprofv3 --pmc $c --output-format csv -d $out/hbm_$c -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras $BARGS > $out/hbm_$c.log 2>&1 || { tail -5 $out/hbm_$c.log; exit 1; }
 done
 python3 - $out <<'PY' > $out/hbm.txt
 import csv, glob, sys
