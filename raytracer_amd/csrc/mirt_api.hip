@@ -282,10 +282,9 @@ static _Float16 f16_round_down(double x) { /* the largest f16 <= x (finite range
     if ((b & 0x7FFFu) == 0) return f16_from_bits(0x8001u); /* below +-0: the smallest negative subnormal */
     return f16_from_bits((b & 0x8000u) ? (uint16_t)(b + 1) : (uint16_t)(b - 1));
 }
-/* Does the scene qualify at all?  (resident, finite) */
+/* Does the scene qualify at all?  (finite extents) */
 static void mx_init(mirt_scene* s, const std::vector<MxBall>& balls /* one per sorted slot */) {
     s->mx_balls.clear();
-    if (balls.size() > MIRT_LDS_RECORDS || s->n_materials > 0x10000u) return;
     double R = 0;
     for (const MxBall& b : balls)
         if (b.real) {
@@ -335,7 +334,7 @@ static int mx_ensure(const mirt_scene* s, int e) {
     const double sc = std::ldexp(1.0, e);
     const double eps = 1.0 / 16777216.0, F = 1.0 / 2097152.0; /* 2^-24, 2^-21 */
     const size_t ntiles = (balls.size() + 31) / 32;
-    std::vector<uint4> SM(std::max<size_t>(ntiles, 1) * 64);
+    std::vector<uint4> SM((ntiles + 1) * 64); /* + one tile: the streaming loop prefetches one ahead */
     for (size_t T = 0; T < ntiles; ++T)
         for (uint32_t l = 0; l < 64; ++l) {
             const uint32_t i = l % 32, sub = (i / 4) % 2, r = (i % 4) + 4 * (i / 8);

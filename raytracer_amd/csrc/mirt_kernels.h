@@ -470,15 +470,20 @@ struct MxLds {
     float4 B[MIRT_LDS_RECORDS];
     uint16_t mat[MIRT_LDS_RECORDS];
     uint32_t ent[MIRT_F32_WAVES][MIRT_ENT_CAP][MIRT_WAVE];
-    __device__ inline void fill(const DevScene<float>& sc) { /* the host launches this kernel for resident scenes only */
-        const uint32_t ntiles = (sc.n + 31) / 32;
-        for (uint32_t i = threadIdx.x; i < ntiles * 64; i += blockDim.x) SM[i] = sc.SM[i];
-        for (uint32_t i = threadIdx.x; i < sc.n; i += blockDim.x) {
-            A[i] = sc.A[i];
-            B[i] = sc.B[i];
-            mat[i] = (uint16_t)sc.material[i];
+    /* all threads of the block; true when the scene is resident (larger scenes read their operands through L1/L2) */
+    __device__ inline bool fill(const DevScene<float>& sc) {
+        const bool res = sc.n <= MIRT_LDS_RECORDS && sc.n_materials <= 0x10000u;
+        if (res) {
+            const uint32_t ntiles = (sc.n + 31) / 32;
+            for (uint32_t i = threadIdx.x; i < ntiles * 64; i += blockDim.x) SM[i] = sc.SM[i];
+            for (uint32_t i = threadIdx.x; i < sc.n; i += blockDim.x) {
+                A[i] = sc.A[i];
+                B[i] = sc.B[i];
+                mat[i] = (uint16_t)sc.material[i];
+            }
         }
         __syncthreads();
+        return res;
     }
 };
 /* The empty asm statements pin ONE conversion per value: without them instruction selection converts the same f32 twice
@@ -492,6 +497,7 @@ __device__ inline void mx_split(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
     asm volatile("" : "+v"(lo));
 }
+template <bool RES>
 __device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
                                 Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
     best.t = INFINITY;
@@ -532,9 +538,14 @@ __device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w,
         bgx = __builtin_bit_cast(mirt_h8, gx); bgy = __builtin_bit_cast(mirt_h8, gy);
         bex = __builtin_bit_cast(mirt_h8, ex); bey = __builtin_bit_cast(mirt_h8, ey);
     }
-    const mirt_h8* SM = (const mirt_h8*)L.SM;
+    /* sphere operands: the block-resident LDS copy, or (big scenes) straight from L1/L2 - every wave of the chip reads the
+     * same 1 KB per tile, one coalesced 16-byte load per lane, the next tile's already on its way while this one is tested
+     * (the array is padded by one tile) */
+    const mirt_h8* SM = RES ? (const mirt_h8*)L.SM : (const mirt_h8*)sc.SM;
     const uint32_t sub = lane >> 5;
     uint32_t t = 0;
+    mirt_h8 pre = {};
+    if (!RES) pre = SM[lane];
     while (t < ntiles) { /* one pass unless some lane's entry list fills up */
         uint32_t cnt = 0;
         const uint32_t gbase = 2 * t;
@@ -542,7 +553,13 @@ __device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w,
         tlimit = tlimit < ntiles ? tlimit : ntiles;
         bool flush = false;
         for (; t < tlimit && !flush; ++t) {
-            const mirt_h8 a = SM[t * 64 + lane];
+            mirt_h8 a;
+            if (RES) {
+                a = SM[t * 64 + lane];
+            } else {
+                a = pre;
+                pre = SM[(t + 1) * 64 + lane];
+            }
             const mirt_f16v zero = {};
             uint32_t mx = 2 * t - gbase + sub, my = mx;
             {
@@ -599,7 +616,8 @@ __device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w,
                 if (m != 0) {
                     const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
                     m &= m - 1u;
-                    narrow_test(sc, GeomLdsT<MxLds>{L}, gi - bit, ray, a_true, tmin, best);
+                    if (RES) narrow_test(sc, GeomLdsT<MxLds>{L}, gi - bit, ray, a_true, tmin, best);
+                    else narrow_test(sc, GeomGlobal<float>{sc}, gi - bit, ray, a_true, tmin, best);
                     ++narrow_count;
                 }
             }
@@ -834,17 +852,20 @@ template <bool RES> struct TracerF32 {
     __device__ inline uint32_t material(uint32_t idx) const { return RES ? (uint32_t)L.mat[idx] : sc.material[idx]; }
 };
 
-struct TracerF32Mx {
+template <bool RES> struct TracerF32Mx {
     typedef float Real;
     static constexpr bool RESUMABLE = false;
     const DevScene<float>& sc;
     MxLds& L;
     uint32_t w;
     __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
-        trace_mx(sc, L, w, lane, active, ray, tmin, best, nc, pt);
+        trace_mx<RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
     }
-    __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const { return make_hit(sc, GeomLdsT<MxLds>{L}, c, ray); }
-    __device__ inline uint32_t material(uint32_t idx) const { return (uint32_t)L.mat[idx]; }
+    __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const {
+        if (RES) return make_hit(sc, GeomLdsT<MxLds>{L}, c, ray);
+        return make_hit(sc, GeomGlobal<float>{sc}, c, ray);
+    }
+    __device__ inline uint32_t material(uint32_t idx) const { return RES ? (uint32_t)L.mat[idx] : sc.material[idx]; }
 };
 
 template <class Store, bool DYN> struct TracerF32Bvh {
@@ -1071,10 +1092,15 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK) void primary_hits_kernel_f32(DevSce
 __global__ __launch_bounds__(MIRT_F32_BLOCK) void primary_hits_kernel_f32_mx(DevScene<float> sc, DevCamera<float> cam, DevPart part, uint32_t* __restrict__ out_id,
                                                                              float* __restrict__ out_t) {
     __shared__ MxLds L;
-    L.fill(sc);
+    const bool res = L.fill(sc);
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    TracerF32Mx tr{sc, L, w};
-    primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_F32_WAVES + w, lane, out_id, out_t);
+    if (res) {
+        TracerF32Mx<true> tr{sc, L, w};
+        primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_F32_WAVES + w, lane, out_id, out_t);
+    } else {
+        TracerF32Mx<false> tr{sc, L, w};
+        primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_F32_WAVES + w, lane, out_id, out_t);
+    }
 }
 
 __global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel_f32_bvh(DevScene<float> sc, DevCamera<float> cam, DevPart part, uint32_t* __restrict__ out_id,
@@ -1317,14 +1343,19 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
     }
 }
 
-/* the same with the broad phase on the matrix pipe (resident scenes whose coordinates fit the split-f16 operands) */
+/* the same with the broad phase on the matrix pipe (scenes whose coordinates fit the split-f16 operands) */
 __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32_mx(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
                                                                        float* __restrict__ partial, DevStats* __restrict__ stats) {
     __shared__ MxLds L;
-    L.fill(sc);
+    const bool res = L.fill(sc);
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    TracerF32Mx tr{sc, L, w};
-    render_body(tr, sc, cam, part, rp, partial, stats, lane);
+    if (res) {
+        TracerF32Mx<true> tr{sc, L, w};
+        render_body(tr, sc, cam, part, rp, partial, stats, lane);
+    } else {
+        TracerF32Mx<false> tr{sc, L, w};
+        render_body(tr, sc, cam, part, rp, partial, stats, lane);
+    }
 }
 
 /* ---- K2b (+K3): add the chunks of a pixel in chunk order, scale by 1/spp (camera.rs:246), gamma + quantise

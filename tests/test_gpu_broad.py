@@ -49,10 +49,23 @@ def test_matrix_maps_random_scenes(oracle, n, seed):
     assert len(np.unique(ids)) > min(n, 100) // 8
 
 
-def test_larger_scenes_stay_on_the_valu_kernel(oracle):
-    sc = presets.stress_scene(1100, seed=7)
-    cam = presets.stress_camera(96, 0, 50)
-    _maps(oracle, sc, cam, expect="valu")
+@pytest.mark.parametrize("n", [1025, 1100, 6000])
+def test_larger_scenes_stream_their_operands(oracle, n):
+    """More than 1024 spheres: the operands no longer fit the LDS copy and are read tile by tile through L1/L2."""
+    sc = presets.stress_scene(n, seed=7)
+    cam = presets.stress_camera(128, 0, 50)
+    ids = _maps(oracle, sc, cam)
+    assert len(np.unique(ids)) > 100
+
+
+def test_streaming_render_is_bit_identical_on_both_broad_phases():
+    sc, cam = presets.stress_scene(3000, seed=5), presets.stress_camera(96, 4, 12)
+    assert cam.closest_hit_kind(sc, precision=abi.F32) == "matrix"
+    a, a8 = cam.render_arrays(sc, precision=abi.F32, seed=4)
+    seg = cam.last_stats["segments"]
+    b, b8 = cam.render_arrays(sc, precision=abi.F32, seed=4, accel="valu")
+    assert cam.last_stats["segments"] == seg
+    assert np.array_equal(bits(a), bits(b)) and np.array_equal(a8, b8)
 
 
 def _moving_mix(scale, n=300, seed=9):
