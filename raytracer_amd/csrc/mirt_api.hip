@@ -414,8 +414,13 @@ static int check_common(const mirt_scene* s, const mirt_camera* cam, const mirt_
 /* Brute-force f32 calls run their broad phase on the matrix pipe when the scene and the camera allow it (mx_pick). */
 static bool use_mx(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, int* e) {
     if (o->precision != MIRT_F32 || (o->flags & (MIRT_FLAG_BVH | MIRT_FLAG_VALU_BROAD))) return false;
-    if (const char* v = getenv("MIRT_BROAD")) /* tuning knob: valu | matrix */
+    bool forced = false;
+    if (const char* v = getenv("MIRT_BROAD")) { /* tuning knob: valu | matrix (matrix = also for scenes below the size threshold) */
         if (!strcmp(v, "valu")) return false;
+        forced = !strcmp(v, "matrix");
+    }
+    /* a handful of spheres is tested faster than the ray's operands are split and exchanged (3 spheres at 4K: 9.6 vs 10.1 ms) */
+    if (s->true_n < 24 && !forced) return false;
     return mx_pick(s, cam, e);
 }
 static uint32_t grid_for(uint32_t W, uint32_t local_rows, uint32_t waves_per_block) {
@@ -742,10 +747,15 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
                 fprintf(stderr, "[mirt phase timing] wave-cycles:");
                 for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h.phase_cycles[i] / (double)(tot ? tot : 1));
                 fprintf(stderr, "  (total %.3g cycles, %.0f per wave-iteration)\n", (double)tot, (double)tot / (double)(h.wave_iters ? h.wave_iters : 1));
+#ifdef MIRT_ACTIVE_HIST
+                fprintf(stderr, "[mirt active-lane histogram] wave-iterations with 1-2 / 3-8 / 9-32 / 33-64 active lanes: %llu %llu %llu %llu of %llu\n", h.bvh_lane_steps,
+                        h.bvh_wave_steps, h.bvh_leaf_rounds, h.bvh_lane_leaves, h.wave_iters);
+#else
                 if (h.bvh_wave_steps)
                     fprintf(stderr, "[mirt phase timing] tree: %.1f node steps per segment, %.1f wave-level steps and %.2f leaf rounds per wave-iteration, %.2f leaves per segment\n",
                             (double)h.bvh_lane_steps / (double)(h.segments ? h.segments : 1), (double)h.bvh_wave_steps / (double)(h.wave_iters ? h.wave_iters : 1),
                             (double)h.bvh_leaf_rounds / (double)(h.wave_iters ? h.wave_iters : 1), (double)h.bvh_lane_leaves / (double)(h.segments ? h.segments : 1));
+#endif
                 double span = (double)(h.end_max - ~h.inv_start_max) * 1e-5; /* 100 MHz ticks -> ms */
                 double life = (double)h.life_sum / (double)(h.n_waves ? h.n_waves : 1) * 1e-5;
                 fprintf(stderr, "[mirt phase timing] %llu waves, first start -> last end %.3f ms, mean wave lifetime %.3f ms (%.1f%% of the span)\n",

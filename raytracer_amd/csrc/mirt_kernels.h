@@ -626,6 +626,46 @@ __device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w,
     }
 }
 
+/* ---- a few rays left in the wave: spheres across the lanes ------------------------------------------
+ * Near the end of a launch a wave may be down to one or two live paths (a path through glass runs to the depth limit
+ * while every other lane has finished); the tile loops above would still charge it the full price of 64 rays per
+ * segment.  Here each live ray is broadcast in turn (v_readlane), every lane runs the exact test on spheres
+ * lane, lane + 64, ... and the wave reduces (t, hit id) to the minimum - the same closest hit, since the exact test is
+ * all the broad phases ever filter for.  ~8 rounds of one exact test per ray for the bench scene instead of 16 tiles of
+ * matrix work: the tail of an 8-GPU band shrinks from ~1 ms to ~0.2 ms. */
+#define MIRT_FEW_LANES 4u
+template <class R, class G>
+__device__ inline void trace_few(const DevScene<R>& sc, const G& geo, uint32_t lane, unsigned long long live, const RayT<R>& ray, R tmin, Closest<R>& best,
+                                 uint32_t& narrow_count) {
+    static_assert(sizeof(R) == 4, "f32 kernels only");
+    best.t = INFINITY;
+    best.idx = 0xFFFFFFFFu;
+    while (live != 0ull) {
+        const int L = __ffsll((long long)live) - 1;
+        live &= live - 1ull;
+        auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); };
+        const RayT<float> r = {{bc(ray.o.x), bc(ray.o.y), bc(ray.o.z)}, {bc(ray.d.x), bc(ray.d.y), bc(ray.d.z)}, bc(ray.tm)};
+        const float a = ray_a(r.d);
+        Closest<float> b = {INFINITY, 0xFFFFFFFFu};
+        for (uint32_t i = lane; i < sc.n; i += MIRT_WAVE) narrow_test(sc, geo, i, r, a, tmin, b); /* dummy records never hit */
+        /* minimum over the wave of (t, hit id): positive floats order like their bit patterns */
+        uint32_t kt = __float_as_uint(b.t), kid = b.idx != 0xFFFFFFFFu ? sc.orig_id[b.idx] : 0xFFFFFFFFu, kidx = b.idx;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t ot = (uint32_t)__shfl_xor((int)kt, o, 64), oid = (uint32_t)__shfl_xor((int)kid, o, 64), oidx = (uint32_t)__shfl_xor((int)kidx, o, 64);
+            const bool take = ot < kt || (ot == kt && oid < kid);
+            kt = take ? ot : kt;
+            kid = take ? oid : kid;
+            kidx = take ? oidx : kidx;
+        }
+        if ((int)lane == L) {
+            best.t = __uint_as_float(kt);
+            best.idx = kidx;
+            narrow_count += (sc.n + MIRT_WAVE - 1) / MIRT_WAVE; /* charged to the ray's lane: exact tests per lane and ray */
+        }
+    }
+}
+
 /* ---- f32, MIRT_FLAG_BVH: closest hit through the bounding-volume tree --------------------------------
  * Per-lane stack traversal (stack in LDS) of the tree built by mirt_scene_create; the leaves hold the same (M, w)
  * bounding records as the brute-force broad phase and are tested with the same expression, the survivors go through
@@ -859,7 +899,14 @@ template <bool RES> struct TracerF32Mx {
     MxLds& L;
     uint32_t w;
     __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
-        trace_mx<RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
+        const unsigned long long live = __ballot(active);
+        if ((uint32_t)__popcll(live) <= MIRT_FEW_LANES) {
+            if (RES) trace_few(sc, GeomLdsT<MxLds>{L}, lane, live, ray, tmin, best, nc);
+            else trace_few(sc, GeomGlobal<float>{sc}, lane, live, ray, tmin, best, nc);
+            pt.stamp(PH_NARROW);
+        } else {
+            trace_mx<RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
+        }
     }
     __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const {
         if (RES) return make_hit(sc, GeomLdsT<MxLds>{L}, c, ray);
@@ -1210,6 +1257,12 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
         }
         if (__ballot(has_work) == 0ull) break;
         ++n_iter;
+#ifdef MIRT_ACTIVE_HIST
+        {
+            const uint32_t na_ = (uint32_t)__popcll(__ballot(has_work));
+            if (lane == 0) atomicAdd((unsigned long long*)sc.dbg + (na_ <= 2 ? 5 : na_ <= 8 ? 6 : na_ <= 32 ? 7 : 8), 1ull);
+        }
+#endif
         pt.stamp(PH_QUEUE);
         /* ---- camera ray for lanes that start a sample (camera.rs:209-230 / 248-252) ------------------- */
         if (need_ray) {

@@ -11,6 +11,13 @@ from raytracer_amd.api import Camera, Dielectric, Lambertian, Metal, Scene, Sphe
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _matrix_pipe_for_small_scenes_too(monkeypatch):
+    """Scenes of fewer than 24 spheres default to the vector ALU (cheaper than preparing a ray's operands); the tests here
+    want the matrix pipe wherever the operands fit, so they set the library's tuning knob."""
+    monkeypatch.setenv("MIRT_BROAD", "matrix")
+
+
 def bits(a):
     return a.view(np.uint32)
 
@@ -172,6 +179,12 @@ def test_render_is_bit_identical_on_both_broad_phases(name):
     assert st_a["segments"] == st_b["segments"] and st_a["sphere_tests"] == st_b["sphere_tests"]
     # the matrix pipe's margins are a little wider: a few more candidates, never fewer hits
     assert st_a["narrow_tests"] <= 1.1 * st_b["narrow_tests"] + 64
+
+
+def test_tiny_scenes_default_to_the_vector_alu(monkeypatch):
+    monkeypatch.delenv("MIRT_BROAD")
+    assert presets.default_camera(64, 0, 5).closest_hit_kind(presets.mars_texture_scene(), precision=abi.F32) == "valu"
+    assert presets.bouncing_balls_camera(64, 0, 5).closest_hit_kind(presets.bouncing_balls_scene(1), precision=abi.F32) == "matrix"
 
 
 def test_inside_a_sphere_and_degenerate_inputs(oracle):
