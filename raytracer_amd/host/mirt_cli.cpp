@@ -3,7 +3,7 @@
  * (/root/reference/src/main.rs:29-134) does with one hard-coded scene and camera, for all five of its scenes.
  *
  *   mirt_cli render --scene mars|bouncing_balls|scene|scene2|blur_scene [--width 400] [--spp 100] [--depth 50]
- *                   [--seed 1] [--layout-seed 1] [--precision 64|32] [--accel brute|bvh] [--textures DIR] [--out FILE]
+ *                   [--seed 1] [--layout-seed 1] [--precision 64|32] [--accel brute|valu|bvh] [--textures DIR] [--out FILE]
  *        PPM P3 on stdout (or FILE), like the reference.  --spp 0 = the no-anti-aliasing branch.
  *   mirt_cli decode IN.jpg OUT.ppm      the image loader alone (binary PPM out)
  */
@@ -18,7 +18,7 @@ using namespace raytracer;
 
 static int usage() {
     std::cerr << "usage: mirt_cli render --scene NAME [--width W] [--spp N] [--depth D] [--seed S] [--layout-seed S] [--precision 64|32]\n"
-                 "                       [--accel brute|bvh] [--textures DIR] [--out FILE]\n"
+                 "                       [--accel brute|valu|bvh] [--textures DIR] [--out FILE]\n"
                  "       mirt_cli decode IN.jpg OUT.ppm\n";
     return 2;
 }
@@ -73,6 +73,7 @@ int main(int argc, char** argv) {
         cam.seed = std::strtoull(opt["--seed"].c_str(), nullptr, 10);
         cam.precision = opt["--precision"] == "32" ? MIRT_F32 : MIRT_F64;
         cam.use_bvh = opt["--accel"] == "bvh";
+        cam.valu_broad = opt["--accel"] == "valu";
         if (opt["--out"].empty()) {
             cam.render(scene, std::cout);
         } else {

@@ -261,6 +261,7 @@ class Camera {
     uint64_t seed = 0;                 /* key of the counter RNG (the reference seeds from the OS) */
     mirt_precision precision = MIRT_F64;
     bool use_bvh = false;              /* MIRT_FLAG_BVH: bounding-volume tree instead of the brute-force loop (MIRT_F32 only) */
+    bool valu_broad = false;           /* MIRT_FLAG_VALU_BROAD: keep the f32 brute-force broad phase on the vector ALU */
     mirt_stats last_stats{};
 
     /* The ten positional Options of camera.rs:123-134 with the defaults of :135-149 and the arithmetic of :151-182. */
@@ -323,7 +324,7 @@ class Camera {
         mirt_opts o{};
         o.precision = precision;
         o.seed = seed;
-        o.flags = use_bvh ? MIRT_FLAG_BVH : 0u;
+        o.flags = (use_bvh ? MIRT_FLAG_BVH : 0u) | (valu_broad ? MIRT_FLAG_VALU_BROAD : 0u);
         check(mirt_render(scene.handle(), &pod, &o, nullptr, px.data(), &last_stats));
         return px;
     }
