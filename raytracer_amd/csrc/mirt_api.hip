@@ -494,16 +494,25 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     RenderParams rp;
     rp.nsamples = cam->samples_per_pixel ? cam->samples_per_pixel : 1u;
     choose_chunks(n_pixels, rp.nsamples, sizeof(R), &rp.chunk, &rp.chunks);
-    if (n_pixels * rp.chunks > 0xFFFFFF00ull) return fail(MIRT_ERR_TOO_LARGE, "too many work items for one launch");
-    rp.n_items = (uint32_t)(n_pixels * rp.chunks);
+    /* queue order: passes of G = 2^g_shift chunks (render_body).  Long launches (>= 128 items per lane of the chip) keep all
+     * chunks of a pixel together, short ones - an 8-GPU band of the bench frame has 63 - use passes of 4 (measured:
+     * profiles/r01_microbench.txt); MIRT_GROUP_CHUNKS is the tuning knob */
+    uint32_t G = n_pixels * rp.chunks >= 128ull * 1024ull * (uint64_t)s->n_cus ? 64u : 4u;
+    if (const char* e = getenv("MIRT_GROUP_CHUNKS")) G = (uint32_t)std::max(1, atoi(e));
+    rp.g_shift = 0;
+    while ((2u << rp.g_shift) <= G && (2u << rp.g_shift) <= rp.chunks) ++rp.g_shift;
+    const uint64_t passes = (rp.chunks + (1u << rp.g_shift) - 1) >> rp.g_shift;
+    if (n_pixels * (passes << rp.g_shift) > 0xFFFFFF00ull) return fail(MIRT_ERR_TOO_LARGE, "too many work items for one launch");
+    rp.n_items = (uint32_t)(n_pixels * (passes << rp.g_shift)); /* queue slots; those beyond the last chunk are skipped */
     rp.k0 = (uint32_t)seed;
     rp.k1 = (uint32_t)(seed >> 32);
     rp.tail_items = 0;
-    rp.d_chunks = make_fastdiv(rp.chunks);
+    rp.n_pixels = (uint32_t)n_pixels;
+    rp.d_pg = make_fastdiv(rp.n_pixels << rp.g_shift);
     rp.d_W = make_fastdiv(cam->img_width);
     rp.d_strip = make_fastdiv(part.strip_rows);
     rp.keep_num = 0;
-    size_t need = (size_t)rp.n_items * 3 * sizeof(R);
+    size_t need = (size_t)n_pixels * rp.chunks * 3 * sizeof(R);
     if (need > s->partial_bytes) {
         if (s->partial) (void)hipFree(s->partial);
         s->partial = nullptr;

@@ -1174,7 +1174,9 @@ struct RenderParams {
     uint32_t nsamples;   /* samples per pixel (1 when anti-aliasing is off) */
     uint32_t k0, k1;     /* RNG key */
     uint32_t tail_items; /* queue tail served in batches of one item per lane (guided self-scheduling) */
-    FastDiv d_chunks, d_W, d_strip; /* divisions by chunks, image width and strip height when an item is decoded */
+    FastDiv d_pg, d_W, d_strip; /* divisions by n_pixels << g_shift, image width and strip height when an item is decoded */
+    uint32_t n_pixels;   /* band pixels */
+    uint32_t g_shift;    /* queue order: 2^g_shift consecutive chunks of a pixel sit next to each other (see render_body) */
     uint32_t keep_num;   /* resumable tree traversal: go on while >= keep_num/64 of the traversing lanes are still at it (0: run to the end) */
 };
 
@@ -1215,9 +1217,10 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
             if (!has_work && rank < take) got = q_next + rank;
             q_next += take;
             if (take < n_idle && !exhausted) { /* reserve the next batch: one atomic per wave per batch */
-                /* guided: near the end of the queue (judged by the last head this wave saw) reserve one item per lane
-                 * only, so that no wave sits on a backlog while others have run dry */
-                const uint32_t batch = q_end + rp.tail_items >= rp.n_items ? MIRT_WAVE : MIRT_QUEUE_BATCH;
+                /* guided: near the end of the queue (judged by the last head this wave saw) reserve exactly what the idle
+                 * lanes take now, so that no wave sits on a backlog - behind 64 lanes of long paths - while others have run
+                 * dry (traced: waves were still finding reserved items 0.7 ms after the first one saw the queue empty) */
+                const uint32_t batch = q_end + rp.tail_items >= rp.n_items ? n_idle - take : MIRT_QUEUE_BATCH;
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&stats->queue_head, batch);
                 base = __builtin_amdgcn_readfirstlane(base);
@@ -1237,9 +1240,16 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 /* the queue runs through the band from its LAST pixel to its first: the sky gradient is the only light
                  * and cameras look roughly level, so the cheap one-segment paths (sky, top rows) end up in the tail
                  * of the launch and the long bounce chains at its start */
+                /* ... in passes of G = 2^g_shift chunks: (pass, pixel, chunk within the pass).  G trades two things: the 64
+                 * items a wave takes together should share pixels (rays of one pixel have the same candidates and the same
+                 * tree walk: G = all chunks is 4 % faster per segment than G = 1 on the bench frame), but 64 chunks of ONE
+                 * pixel on a glass ball are 64 paths to the depth limit that stall the wave and everything it has reserved
+                 * (short launches - an 8-GPU band - want a small G).  Slots beyond the last chunk (padding of the last
+                 * pass) are skipped. */
                 const uint32_t rev = rp.n_items - 1u - got;
-                item = rev;
-                const uint32_t pl = fastdiv(rev, rp.d_chunks), ch = rev - pl * rp.chunks; /* band pixel, row-major; chunk */
+                const uint32_t pass = fastdiv(rev, rp.d_pg), rem = rev - pass * (rp.n_pixels << rp.g_shift);
+                const uint32_t pl = rem >> rp.g_shift, ch = (pass << rp.g_shift) + (rem & ((1u << rp.g_shift) - 1u)); /* band pixel, row-major; chunk */
+                item = ch * rp.n_pixels + pl; /* partial sums are chunk-major: resolve_kernel reads them coalesced */
                 const uint32_t ly = fastdiv(pl, rp.d_W);
                 lx = pl - ly * cam.W;
                 gy = ly; /* part_global_row(part, ly) */
@@ -1251,8 +1261,8 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 sample = ch * rp.chunk;
                 s_end = sample + rp.chunk < rp.nsamples ? sample + rp.chunk : rp.nsamples;
                 acc = {(R)0.0, (R)0.0, (R)0.0};
-                has_work = true;
-                need_ray = true;
+                has_work = ch < rp.chunks;
+                need_ray = has_work;
             }
         }
         if (__ballot(has_work) == 0ull) break;
@@ -1419,8 +1429,10 @@ __global__ void resolve_kernel(const R* __restrict__ partial, DevCamera<R> cam, 
     uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
     if (pl >= n_pixels) return;
     V3<R> acc = {(R)0.0, (R)0.0, (R)0.0};
-    const R* p = partial + (size_t)pl * rp.chunks * 3;
-    for (uint32_t c = 0; c < rp.chunks; ++c) acc = acc + V3<R>{p[3 * c], p[3 * c + 1], p[3 * c + 2]};
+    for (uint32_t c = 0; c < rp.chunks; ++c) { /* chunk-major: neighbouring threads read neighbouring sums */
+        const R* p = partial + ((size_t)c * n_pixels + pl) * 3;
+        acc = acc + V3<R>{p[0], p[1], p[2]};
+    }
     if (cam.spp > 0) acc = acc * ((R)1.0 / (R)cam.spp); /* samples_scale, camera.rs:50,246 */
     uint32_t ly = pl / cam.W, lx = pl - ly * cam.W;
     uint32_t row = part.compact ? ly : part_global_row(part, ly);
