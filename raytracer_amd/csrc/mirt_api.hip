@@ -512,7 +512,7 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     rp.d_W = make_fastdiv(cam->img_width);
     rp.d_strip = make_fastdiv(part.strip_rows);
     rp.keep_num = 0;
-    size_t need = (size_t)n_pixels * rp.chunks * 3 * sizeof(R);
+    size_t need = (size_t)rp.n_items * 3 * sizeof(R); /* one slot per queue position */
     if (need > s->partial_bytes) {
         if (s->partial) (void)hipFree(s->partial);
         s->partial = nullptr;

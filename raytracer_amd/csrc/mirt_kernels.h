@@ -1249,7 +1249,7 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 const uint32_t rev = rp.n_items - 1u - got;
                 const uint32_t pass = fastdiv(rev, rp.d_pg), rem = rev - pass * (rp.n_pixels << rp.g_shift);
                 const uint32_t pl = rem >> rp.g_shift, ch = (pass << rp.g_shift) + (rem & ((1u << rp.g_shift) - 1u)); /* band pixel, row-major; chunk */
-                item = ch * rp.n_pixels + pl; /* partial sums are chunk-major: resolve_kernel reads them coalesced */
+                item = rev; /* partial sums sit in queue order: the lanes of a wave store next to each other */
                 const uint32_t ly = fastdiv(pl, rp.d_W);
                 lx = pl - ly * cam.W;
                 gy = ly; /* part_global_row(part, ly) */
@@ -1429,9 +1429,12 @@ __global__ void resolve_kernel(const R* __restrict__ partial, DevCamera<R> cam, 
     uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
     if (pl >= n_pixels) return;
     V3<R> acc = {(R)0.0, (R)0.0, (R)0.0};
-    for (uint32_t c = 0; c < rp.chunks; ++c) { /* chunk-major: neighbouring threads read neighbouring sums */
-        const R* p = partial + ((size_t)c * n_pixels + pl) * 3;
-        acc = acc + V3<R>{p[0], p[1], p[2]};
+    /* queue order (render_body): [pass][pixel][chunk within the pass]; summed in chunk order whatever the pass size */
+    const uint32_t G = 1u << rp.g_shift;
+    const R* p = partial + ((size_t)pl << rp.g_shift) * 3;
+    for (uint32_t c0 = 0; c0 < rp.chunks; c0 += G, p += ((size_t)n_pixels << rp.g_shift) * 3) {
+        const uint32_t n = rp.chunks - c0 < G ? rp.chunks - c0 : G;
+        for (uint32_t k = 0; k < n; ++k) acc = acc + V3<R>{p[3 * k], p[3 * k + 1], p[3 * k + 2]};
     }
     if (cam.spp > 0) acc = acc * ((R)1.0 / (R)cam.spp); /* samples_scale, camera.rs:50,246 */
     uint32_t ly = pl / cam.W, lx = pl - ly * cam.W;
