@@ -351,7 +351,7 @@ static int mx_ensure(const mirt_scene* s, int e) {
                     M2 += m * m;
                 }
                 const double rho = b.rho * sc, Ml = std::sqrt(M2);
-                const double w = M2 - rho * rho - 256.0 * eps * (M2 + rho * rho) - F * Ml;
+                const double w = M2 - rho * rho - (double)MIRT_MX_MARGIN_TEST * (256.0 * eps * (M2 + rho * rho) + F * Ml);
                 wh = (_Float16)w;
                 wl = f16_round_down(w - (double)wh); /* wh + wl <= w */
             }

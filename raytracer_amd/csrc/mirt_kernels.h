@@ -458,9 +458,12 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
  *   16 of the 32 rows of one column - rows are ordered so that these are 16 consecutive sorted spheres - and the same
  *   swap brings the two 16-bit words of a ray together.  The entry lists and the narrow phase are trace_cons's. */
 #define MIRT_MX_K2MAX 36000.0f
-#define MIRT_MX_SHRINK 0.99998f /* <= 1 - 335 * 2^-24 */
-#define MIRT_MX_FLOOR_LIN 5.2e-7f /* >= 2^-20.9 */
-#define MIRT_MX_FLOOR_ABS 6.0e-8f /* >= 2^-24 */
+#ifndef MIRT_MX_MARGIN_TEST /* diagnostic builds: scale every margin of trace_mx (1 = the derived ones) to see how much slack they carry */
+#define MIRT_MX_MARGIN_TEST 1.0
+#endif
+#define MIRT_MX_SHRINK (1.0f - 2.0e-5f * (float)MIRT_MX_MARGIN_TEST) /* <= 1 - 335 * 2^-24 */
+#define MIRT_MX_FLOOR_LIN (5.2e-7f * (float)MIRT_MX_MARGIN_TEST) /* >= 2^-20.9 */
+#define MIRT_MX_FLOOR_ABS (6.0e-8f * (float)MIRT_MX_MARGIN_TEST) /* >= 2^-24 */
 typedef _Float16 mirt_h8 __attribute__((ext_vector_type(8)));
 typedef float mirt_f16v __attribute__((ext_vector_type(16)));
 typedef uint32_t mirt_u4 __attribute__((ext_vector_type(4)));
