@@ -125,7 +125,7 @@ def main():
     frame = torch.zeros((H, W, 3), dtype=real, device="cuda") if rank == 0 else None
     opts = cam.opts(precision=args.precision, seed=args.seed, strip_rows=S, part_index=rank, part_count=world,
                     flags=abi.FLAG_COMPACT_ROWS | {"brute": 0, "valu": abi.FLAG_VALU_BROAD, "bvh": abi.FLAG_BVH}[args.accel])
-    kind = lib.mirt_closest_hit_kind(ds.handle, C.byref(cam.pod), C.byref(opts))  # 0 valu, 1 matrix pipe, 2 tree, 3 f64
+    kind = lib.mirt_closest_hit_kind(ds.handle, C.byref(cam.pod), C.byref(opts))  # 0 valu, 1 matrix pipe, 2 tree, 3 f64, 4 f64 with the matrix-pipe broad phase
     abi.check(min(kind, 0))
     stream = torch.cuda.current_stream().cuda_stream
     elem = 3 * (4 if args.precision == 32 else 8)
@@ -190,7 +190,8 @@ def main():
                 "seed": args.seed,
                 "closest_hit": ["brute-force LDS tile loop, broad phase on the vector ALU",
                                 "brute-force LDS tile loop, broad-phase dot products on the matrix pipe (split-f16 MFMA), exact narrow phase on the vector ALU",
-                                "bounding-ball tree (MIRT_FLAG_BVH)", "brute-force tile loop, f64"][kind],
+                                "bounding-ball tree (MIRT_FLAG_BVH)", "brute-force tile loop, f64",
+                                "brute-force tile loop, f64: f32 broad phase on the matrix pipe, exact f64 narrow phase and shading"][kind],
             },
             "roofline": {
                 "bound": "valu_fp32",
@@ -201,7 +202,7 @@ def main():
                 # HBM bytes per launch of this kernel, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE in separate passes
                 # (profiles/r01_v5_hbm_traffic.txt; not re-measured by this script).  Only quoted for the workload it was taken on.
                 "traffic": 8.3e8 if (args.workload == "balls1080p" and (W, cam.pod.samples_per_pixel, world) == (1920, 64, 1) and kind in (0, 1)) else None,
-                "kernel": ["render_kernel_f32", "render_kernel_f32_mx", "render_kernel_f32_bvh(_lds)", "render_kernel_f64<2>"][kind],
+                "kernel": ["render_kernel_f32", "render_kernel_f32_mx", "render_kernel_f32_bvh(_lds)", "render_kernel_f64<2>", "render_kernel_f64_mx"][kind],
                 "kernel_ms_avg": round(kern_ms / max(1, len(stats)), 3),
                 "flops_per_segment": round(flops / max(seg, 1), 1),
                 "note": "algorithmic flops = 18/static sphere test + 27/moving sphere test + 5/segment (SURVEY.md 8d); rank 0's launches"

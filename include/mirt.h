@@ -123,9 +123,9 @@ typedef enum mirt_precision {
  * precision only).  Same (id, t) for every ray, hence the same image bit for bit; the counterpart of the reference's
  * Bvh::hit (src/scene/bvh.rs:78-92) for scenes where testing every sphere is not affordable. */
 #define MIRT_FLAG_BVH 2u
-/* f32 brute-force loop: keep the broad phase on the vector ALU.  By default scenes of <= 1024 spheres whose extents fit
- * the split-f16 operands run the broad phase's dot products on the matrix pipe (v_mfma_f32_32x32x16_f16); the candidates
- * go through the same exact test either way, so the (id, t) of every ray - and the image - do not depend on this flag. */
+/* Brute-force loop (either precision): keep the broad phase on the vector ALU.  By default scenes whose extents fit the
+ * split-f16 operands run the broad phase's dot products on the matrix pipe (v_mfma_f32_32x32x16_f16); the candidates go
+ * through the same exact test either way, so the (id, t) of every ray - and the image - do not depend on this flag. */
 #define MIRT_FLAG_VALU_BROAD 4u
 
 /* Which rows a call renders: rows are grouped in strips of `strip_rows`; strip s is owned when
@@ -205,7 +205,8 @@ uint32_t mirt_part_rows(uint32_t height, uint32_t strip_rows, uint32_t part_inde
 
 /* Which closest-hit front end a render / primary-hits call with these arguments runs (no reference counterpart; for
  * benchmarks and tests): 0 = brute force with the broad phase on the vector ALU, 1 = brute force with the broad phase
- * on the matrix pipe, 2 = bounding-volume tree, 3 = f64 brute force; negative = MIRT_ERR_* for invalid arguments. */
+ * on the matrix pipe, 2 = bounding-volume tree, 3 = f64 brute force on the vector ALU, 4 = f64 brute force with the (f32)
+ * broad phase on the matrix pipe; negative = MIRT_ERR_* for invalid arguments. */
 int mirt_closest_hit_kind(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts);
 
 /* Counter-based RNG, exposed for known-answer tests: Philox4x32-10 block.  out[4]. */

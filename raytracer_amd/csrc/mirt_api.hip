@@ -49,9 +49,12 @@ struct mirt_scene {
     bool bvh_ok = false;
     /* matrix-pipe broad phase (trace_mx): the bounding balls on the host, and split-f16 sphere operands on the device for
      * every power-of-two scale a call has asked for so far (the scale depends on the camera position, see mx_pick) */
-    std::vector<MxBall> mx_balls; /* one per sorted slot; empty when the scene does not qualify */
-    double mx_R = 0;              /* max (|M| + rho) */
-    mutable std::vector<std::pair<int, uint4*>> mx_cache;
+    struct MxSet {
+        std::vector<MxBall> balls; /* one per sorted slot; empty when the scene does not qualify */
+        double R = 0;              /* max (|M| + rho) */
+        mutable std::vector<std::pair<int, uint4*>> cache;
+    };
+    MxSet mx32, mx64;             /* balls around the f32 spheres (what the f32 kernels test) and around the f64 ones */
     mutable uint4* SM = nullptr;  /* operands and scale of the call being launched */
     mutable float mx_scale = 1.f;
     DevStats* stats = nullptr; /* one per scene: calls on one scene handle are not re-entrant */
@@ -283,8 +286,8 @@ static _Float16 f16_round_down(double x) { /* the largest f16 <= x (finite range
     return f16_from_bits((b & 0x8000u) ? (uint16_t)(b + 1) : (uint16_t)(b - 1));
 }
 /* Does the scene qualify at all?  (finite extents) */
-static void mx_init(mirt_scene* s, const std::vector<MxBall>& balls /* one per sorted slot */) {
-    s->mx_balls.clear();
+static void mx_init(mirt_scene::MxSet& set, const std::vector<MxBall>& balls /* one per sorted slot */) {
+    set.balls.clear();
     double R = 0;
     for (const MxBall& b : balls)
         if (b.real) {
@@ -292,8 +295,8 @@ static void mx_init(mirt_scene* s, const std::vector<MxBall>& balls /* one per s
             if (!(ext < 1e30)) return; /* NaN / inf / absurd extents: the VALU kernel copes, f16 does not */
             R = std::max(R, ext);
         }
-    s->mx_R = R;
-    s->mx_balls = balls;
+    set.R = R;
+    set.balls = balls;
 }
 /* The scale 2^e of a call: rays start at the lens or on a sphere, so with `reach` = the lens's largest distance from the
  * origin every ray has |O| <= max(R, reach); the operands fit the f16 range when R 2^e <= 64 and reach 2^e <= 180
@@ -301,12 +304,12 @@ static void mx_init(mirt_scene* s, const std::vector<MxBall>& balls /* one per s
  * outside the scene, or a scene of tiny spheres around a huge one, makes it large against rho^2: where that is the
  * case for more than a quarter of the spheres they would be candidates for every ray passing anywhere near them, and
  * the call stays on the VALU kernel. */
-static bool mx_pick(const mirt_scene* s, const mirt_camera* cam, int* e_out) {
-    if (s->mx_balls.empty() && s->n != 0) return false;
+static bool mx_pick(const mirt_scene* s, const mirt_scene::MxSet& set, const mirt_camera* cam, int* e_out) {
+    if (set.balls.empty() && s->n != 0) return false;
     auto len = [](const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
     const double reach = len(cam->lookfrom) + len(cam->disk_u_r) + len(cam->disk_v_r);
     if (!(reach < 1e30)) return false;
-    const double need = std::max(s->mx_R, reach * (64.0 / 180.0));
+    const double need = std::max(set.R, reach * (64.0 / 180.0));
     int e = 0;
     if (need > 0) {
         (void)std::frexp(64.0 / need, &e); /* 64 / need = m 2^e, m in [0.5, 1)  ->  2^(e-1) <= 64 / need */
@@ -315,7 +318,7 @@ static bool mx_pick(const mirt_scene* s, const mirt_camera* cam, int* e_out) {
     if (e < -100 || e > 100) return false;
     const double sc = std::ldexp(1.0, e);
     size_t real = 0, coarse = 0;
-    for (const MxBall& b : s->mx_balls)
+    for (const MxBall& b : set.balls)
         if (b.real) {
             const double Ml = std::sqrt(b.M[0] * b.M[0] + b.M[1] * b.M[1] + b.M[2] * b.M[2]) * sc, rho = b.rho * sc;
             ++real;
@@ -326,11 +329,11 @@ static bool mx_pick(const mirt_scene* s, const mirt_camera* cam, int* e_out) {
     return true;
 }
 /* Operands for scale 2^e, built on first use and kept with the scene. */
-static int mx_ensure(const mirt_scene* s, int e) {
+static int mx_ensure(const mirt_scene* s, const mirt_scene::MxSet& set, int e) {
     s->mx_scale = (float)std::ldexp(1.0, e);
-    for (const auto& c : s->mx_cache)
+    for (const auto& c : set.cache)
         if (c.first == e) { s->SM = c.second; return MIRT_OK; }
-    const std::vector<MxBall>& balls = s->mx_balls;
+    const std::vector<MxBall>& balls = set.balls;
     const double sc = std::ldexp(1.0, e);
     const double eps = 1.0 / 16777216.0, F = 1.0 / 2097152.0; /* 2^-24, 2^-21 */
     const size_t ntiles = (balls.size() + 31) / 32;
@@ -365,7 +368,7 @@ static int mx_ensure(const mirt_scene* s, int e) {
     HIP_TRY(hipMalloc((void**)&dev, SM.size() * sizeof(uint4)));
     const_cast<mirt_scene*>(s)->allocs.push_back(dev);
     HIP_TRY(hipMemcpy(dev, SM.data(), SM.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    s->mx_cache.emplace_back(e, dev);
+    set.cache.emplace_back(e, dev);
     s->SM = dev;
     return MIRT_OK;
 }
@@ -411,9 +414,11 @@ static int check_common(const mirt_scene* s, const mirt_camera* cam, const mirt_
     }
     return MIRT_OK;
 }
-/* Brute-force f32 calls run their broad phase on the matrix pipe when the scene and the camera allow it (mx_pick). */
+/* Brute-force calls run their broad phase on the matrix pipe when the scene and the camera allow it (mx_pick); the f64
+ * kernels use the balls built around the f64 spheres. */
+static const mirt_scene::MxSet& mx_set(const mirt_scene* s, const mirt_opts* o) { return o->precision == MIRT_F64 ? s->mx64 : s->mx32; }
 static bool use_mx(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, int* e) {
-    if (o->precision != MIRT_F32 || (o->flags & (MIRT_FLAG_BVH | MIRT_FLAG_VALU_BROAD))) return false;
+    if (o->flags & (MIRT_FLAG_BVH | MIRT_FLAG_VALU_BROAD)) return false;
     bool forced = false;
     if (const char* v = getenv("MIRT_BROAD")) { /* tuning knob: valu | matrix (matrix = also for scenes below the size threshold) */
         if (!strcmp(v, "valu")) return false;
@@ -421,7 +426,7 @@ static bool use_mx(const mirt_scene* s, const mirt_camera* cam, const mirt_opts*
     }
     /* a handful of spheres is tested faster than the ray's operands are split and exchanged (3 spheres at 4K: 9.6 vs 10.1 ms) */
     if (s->true_n < 24 && !forced) return false;
-    return mx_pick(s, cam, e);
+    return mx_pick(s, mx_set(s, o), cam, e);
 }
 static uint32_t grid_for(uint32_t W, uint32_t local_rows, uint32_t waves_per_block) {
     uint32_t tiles = ((W + 7) / 8) * ((local_rows + 7) / 8);
@@ -430,9 +435,12 @@ static uint32_t grid_for(uint32_t W, uint32_t local_rows, uint32_t waves_per_blo
 
 /* ---- launches -------------------------------------------------------------------------------- */
 static int launch_primary(const mirt_scene* s, const SceneBuffers<double>& b, const mirt_camera* cam, const DevPart& part, uint32_t* d_id, void* d_t,
-                          hipStream_t st) {
+                          hipStream_t st, bool mx = false) {
     uint32_t grid = grid_for(cam->img_width, part.local_rows, MIRT_WAVES_PER_BLOCK);
     if (grid == 0) return MIRT_OK;
+    if (mx)
+        hipLaunchKernelGGL(primary_hits_kernel_f64_mx, dim3(grid), dim3(MIRT_BLOCK), 0, st, dev_scene<double>(s, b), dev_camera<double>(cam), part, d_id, (double*)d_t);
+    else
     hipLaunchKernelGGL(primary_hits_kernel_f64, dim3(grid), dim3(MIRT_BLOCK), 0, st, dev_scene<double>(s, b), dev_camera<double>(cam), part, d_id, (double*)d_t);
     HIP_TRY(hipGetLastError());
     return MIRT_OK;
@@ -466,11 +474,12 @@ static void choose_chunks(uint64_t n_pixels, uint32_t nsamples, size_t real_byte
 }
 
 /* the two render kernels behind one name */
-static const void* render_fn(double, int) { return (const void*)render_kernel_f64<2>; }
+static const void* render_fn(double, int bvh) { return bvh == 3 ? (const void*)render_kernel_f64_mx : (const void*)render_kernel_f64<2>; }
 static const void* render_fn(float, int bvh) { return bvh == 3 ? (const void*)render_kernel_f32_mx : bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
-static void launch_render_kernel(uint32_t grid, uint32_t block, int, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam,
+static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam,
                                  const DevPart& part, const RenderParams& rp, double* partial, DevStats* stats) {
-    hipLaunchKernelGGL(render_kernel_f64<2>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    if (bvh == 3) hipLaunchKernelGGL(render_kernel_f64_mx, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    else hipLaunchKernelGGL(render_kernel_f64<2>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
 }
 static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<float>& sc, const DevCamera<float>& cam,
                                  const DevPart& part, const RenderParams& rp, float* partial, DevStats* stats) {
@@ -561,10 +570,11 @@ uint32_t mirt_part_rows(uint32_t height, uint32_t strip_rows, uint32_t part_inde
 int mirt_closest_hit_kind(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o) {
     int rc = check_common(s, cam, o);
     if (rc) return rc;
-    if (o->precision == MIRT_F64) return 3;
     if (o->flags & MIRT_FLAG_BVH) return 2;
     int e = 0;
-    return use_mx(s, cam, o, &e) ? 1 : 0;
+    const bool mx = use_mx(s, cam, o, &e);
+    if (o->precision == MIRT_F64) return mx ? 4 : 3;
+    return mx ? 1 : 0;
 }
 void mirt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
@@ -643,6 +653,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
         std::vector<BallRec> balls; /* real spheres only, for the bounding-ball tree */
         balls.reserve(d->n_spheres);
         std::vector<MxBall> mxb(order.size(), MxBall{{0, 0, 0}, 0, false}); /* every sorted slot, for the matrix-pipe operands */
+        std::vector<MxBall> mxb64(order.size(), MxBall{{0, 0, 0}, 0, false});
         for (size_t k = 0; k < order.size(); ++k) {
             if (order[k] == 0xFFFFFFFFu) { S[k].x = S[k].y = S[k].z = 0.f; S[k].w = INFINITY; continue; }
             const mirt_sphere& sp = d->spheres[order[k]];
@@ -669,10 +680,22 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
             S[k].x = Mf[0]; S[k].y = Mf[1]; S[k].z = Mf[2]; S[k].w = wf;
             balls.push_back(BallRec{{(double)Mf[0], (double)Mf[1], (double)Mf[2]}, rho, (uint32_t)k});
             mxb[k] = MxBall{{(double)Mf[0], (double)Mf[1], (double)Mf[2]}, rho, true};
+            {   /* the same centre for the f64 kernels, whose sphere is the description's own: c0 + tm (c1 - c0) in double */
+                double dcd[3] = {0, 0, 0}, off2 = 0, dcl2 = 0;
+                for (int a = 0; a < 3; ++a) {
+                    if (sp.moving) dcd[a] = sp.center1[a] - sp.center0[a];
+                    const double off = sp.center0[a] + 0.5 * dcd[a] - (double)Mf[a];
+                    off2 += off * off;
+                    dcl2 += dcd[a] * dcd[a];
+                }
+                const double rd = sp.radius > 0.0 ? sp.radius : 0.0, dl = std::sqrt(dcl2);
+                mxb64[k] = MxBall{{(double)Mf[0], (double)Mf[1], (double)Mf[2]}, rd + 0.5 * dl + std::sqrt(off2) + 1e-12 * (Ml + dl + rd), true};
+            }
         }
         if ((rc = upload(s, S, &s->S))) { mirt_scene_destroy(s); return rc; }
         if ((rc = build_bvh(s, balls, S))) { mirt_scene_destroy(s); return rc; }
-        mx_init(s, mxb);
+        mx_init(s->mx32, mxb);
+        mx_init(s->mx64, mxb64);
     }
     std::vector<DevStats> st(1);
     memset(st.data(), 0, sizeof(DevStats));
@@ -699,8 +722,8 @@ int mirt_primary_hits_device(const mirt_scene* s, const mirt_camera* cam, const 
     hipStream_t st = (hipStream_t)stream;
     int mx_e = 0;
     const bool mx = use_mx(s, cam, o, &mx_e);
-    if (mx && (rc = mx_ensure(s, mx_e))) return rc;
-    return o->precision == MIRT_F64 ? launch_primary(s, s->f64, cam, part, d_id, d_t, st)
+    if (mx && (rc = mx_ensure(s, mx_set(s, o), mx_e))) return rc;
+    return o->precision == MIRT_F64 ? launch_primary(s, s->f64, cam, part, d_id, d_t, st, mx)
                                     : launch_primary(s, s->f32, cam, part, d_id, d_t, st, (o->flags & MIRT_FLAG_BVH) != 0, mx);
 }
 
@@ -715,14 +738,14 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int mx_e = 0;
     const bool mx = use_mx(s, cam, o, &mx_e);
-    if (mx && (rc = mx_ensure(s, mx_e))) return rc; /* before the timed region: the first call at a new scale uploads operands */
+    if (mx && (rc = mx_ensure(s, mx_set(s, o), mx_e))) return rc; /* before the timed region: the first call at a new scale uploads operands */
     HIP_TRY(hipMemsetAsync(s->stats, 0, sizeof(DevStats), st)); /* counters and the work-queue head */
     if (stats) {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    rc = o->precision == MIRT_F64 ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st, false, false)
+    rc = o->precision == MIRT_F64 ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st, false, mx)
                                   : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0, mx);
     if (stats) {
         if (!rc) {

@@ -468,6 +468,7 @@ typedef _Float16 mirt_h8 __attribute__((ext_vector_type(8)));
 typedef float mirt_f16v __attribute__((ext_vector_type(16)));
 typedef uint32_t mirt_u4 __attribute__((ext_vector_type(4)));
 struct MxLds {
+    static constexpr bool GEOM_LDS = true; /* exact records and material ids of a resident scene are here as well */
     uint4 SM[MIRT_LDS_RECORDS * 2]; /* 64 x 16 B per tile of 32 spheres */
     float4 A[MIRT_LDS_RECORDS];
     float4 B[MIRT_LDS_RECORDS];
@@ -489,6 +490,21 @@ struct MxLds {
         return res;
     }
 };
+/* f64 kernels (256-thread blocks): only the operands and the entry lists; the exact f64 records come through L2 */
+struct MxLds64 {
+    static constexpr bool GEOM_LDS = false;
+    uint4 SM[MIRT_LDS_RECORDS * 2];
+    uint32_t ent[MIRT_WAVES_PER_BLOCK][MIRT_ENT_CAP][MIRT_WAVE];
+    __device__ inline bool fill(const DevScene<double>& sc) {
+        const bool res = sc.n <= MIRT_LDS_RECORDS;
+        if (res) {
+            const uint32_t ntiles = (sc.n + 31) / 32;
+            for (uint32_t i = threadIdx.x; i < ntiles * 64; i += blockDim.x) SM[i] = sc.SM[i];
+        }
+        __syncthreads();
+        return res;
+    }
+};
 /* The empty asm statements pin ONE conversion per value: without them instruction selection converts the same f32 twice
  * for the two users of hi - v_fma_mixlo_f16 (the exact product d * inv rounded once) for the residual and
  * v_cvt_pk_f16_f32 (the f32 product rounded again) for the operand - and the two disagree by one f16 ulp whenever the
@@ -500,21 +516,26 @@ __device__ inline void mx_split(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
     asm volatile("" : "+v"(lo));
 }
-template <bool RES>
-__device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
-                                Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
-    best.t = INFINITY;
+/* R = double (the parity-mode kernels): the same filter on the ray rounded to f32 - Dn is normalised in double first, so
+ * direction and origin are each off by <= 2^-24 relatively, the f32 line passes within 5 eps (|M| + |O|) of the f64 one,
+ * and 6 eps ((|M|+|O|)^2 + rho^2) replaces the 32 eps of the f32 derivation (an f64 discriminant needs ~1e-15) inside the
+ * same 128 eps budget; the balls behind the operands are built around the f64 spheres (mirt_scene_create).  The narrow
+ * phase is the exact f64 test. */
+template <class R, class LDS, bool RES>
+__device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint32_t lane, bool active, const RayT<R>& ray, R tmin,
+                                Closest<R>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+    best.t = (R)INFINITY;
     best.idx = 0xFFFFFFFFu;
-    const float a_true = ray_a(ray.d);
+    const R a_true = ray_a(ray.d);
     const uint32_t ntiles = (sc.n + 31) / 32;
     uint32_t(*ent)[MIRT_WAVE] = L.ent[w];
     /* ---- the ray's operands ---- */
     mirt_h8 bgx, bgy, bex, bey;
     uint32_t amask, omask;
     {
-        const float inv = 1.0f / sqrtf(a_true);
-        const V3<float> Dn = {ray.d.x * inv, ray.d.y * inv, ray.d.z * inv};
-        const V3<float> O = {ray.o.x * sc.mx_scale, ray.o.y * sc.mx_scale, ray.o.z * sc.mx_scale};
+        const R inv = (R)1.0 / m_sqrt(a_true);
+        const V3<float> Dn = {(float)(ray.d.x * inv), (float)(ray.d.y * inv), (float)(ray.d.z * inv)};
+        const V3<float> O = {(float)(ray.o.x * (R)sc.mx_scale), (float)(ray.o.y * (R)sc.mx_scale), (float)(ray.o.z * (R)sc.mx_scale)};
         const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
         const float o2 = __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x));
         const float k2 = o2 * MIRT_MX_SHRINK - __builtin_fmaf(MIRT_MX_FLOOR_LIN, sqrtf(o2), MIRT_MX_FLOOR_ABS);
@@ -585,16 +606,16 @@ __device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w,
             for (uint32_t k_ = 0; k_ < 32; ++k_) { /* exact discriminant >= 0 must imply the candidate bit */
                 const uint32_t i_ = t * 32 + k_;
                 if (i_ >= sc.n) break;
-                float4 sa_ = sc.A[i_];
-                V3<float> C_ = {sa_.x, sa_.y, sa_.z};
+                typename Vec4<R>::type sa_ = sc.A[i_];
+                V3<R> C_ = {sa_.x, sa_.y, sa_.z};
                 if (i_ >= sc.n_static) {
-                    float4 sb_ = sc.B[i_];
-                    C_ = center_at(C_, V3<float>{sb_.x, sb_.y, sb_.z}, ray.tm);
+                    typename Vec4<R>::type sb_ = sc.B[i_];
+                    C_ = center_at(C_, V3<R>{sb_.x, sb_.y, sb_.z}, ray.tm);
                 }
-                float hh_, dd_;
+                R hh_, dd_;
                 disc(C_ - ray.o, ray.d, a_true, sa_.w, hh_, dd_);
                 const uint32_t word_ = k_ < 16 ? mx : my;
-                if (active && dd_ >= 0.0f && ((word_ >> (15 - (k_ & 15u))) & 1u)) atomicAdd(sc.dbg, 1ull);
+                if (active && dd_ >= (R)0.0 && ((word_ >> (15 - (k_ & 15u))) & 1u)) atomicAdd(sc.dbg, 1ull);
             }
 #endif
             /* unconditional writes, conditional advance (cnt <= MIRT_ENT_CAP - 2 here: a nearly full list flushes below) */
@@ -619,8 +640,12 @@ __device__ inline void trace_mx(const DevScene<float>& sc, MxLds& L, uint32_t w,
                 if (m != 0) {
                     const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
                     m &= m - 1u;
-                    if (RES) narrow_test(sc, GeomLdsT<MxLds>{L}, gi - bit, ray, a_true, tmin, best);
-                    else narrow_test(sc, GeomGlobal<float>{sc}, gi - bit, ray, a_true, tmin, best);
+                    if constexpr (LDS::GEOM_LDS) {
+                        if (RES) narrow_test(sc, GeomLdsT<LDS>{L}, gi - bit, ray, a_true, tmin, best);
+                        else narrow_test(sc, GeomGlobal<R>{sc}, gi - bit, ray, a_true, tmin, best);
+                    } else {
+                        narrow_test(sc, GeomGlobal<R>{sc}, gi - bit, ray, a_true, tmin, best);
+                    }
                     ++narrow_count;
                 }
             }
@@ -908,7 +933,7 @@ template <bool RES> struct TracerF32Mx {
             else trace_few(sc, GeomGlobal<float>{sc}, lane, live, ray, tmin, best, nc);
             pt.stamp(PH_NARROW);
         } else {
-            trace_mx<RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
+            trace_mx<float, MxLds, RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
         }
     }
     __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const {
@@ -916,6 +941,19 @@ template <bool RES> struct TracerF32Mx {
         return make_hit(sc, GeomGlobal<float>{sc}, c, ray);
     }
     __device__ inline uint32_t material(uint32_t idx) const { return RES ? (uint32_t)L.mat[idx] : sc.material[idx]; }
+};
+
+template <bool RES> struct TracerF64Mx {
+    typedef double Real;
+    static constexpr bool RESUMABLE = false;
+    const DevScene<double>& sc;
+    MxLds64& L;
+    uint32_t w;
+    __device__ inline void closest(uint32_t lane, bool active, const RayT<double>& ray, double tmin, Closest<double>& best, uint32_t& nc, PhaseTimer& pt) {
+        trace_mx<double, MxLds64, RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
+    }
+    __device__ inline Hit<double> hit(const Closest<double>& c, const RayT<double>& ray) const { return make_hit(sc, GeomGlobal<double>{sc}, c, ray); }
+    __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }
 };
 
 template <class Store, bool DYN> struct TracerF32Bvh {
@@ -1123,6 +1161,19 @@ __global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel_f64(DevScene<d
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     TracerF64 tr{sc, lds_all[w]};
     primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_WAVES_PER_BLOCK + w, lane, out_id, out_t);
+}
+__global__ __launch_bounds__(MIRT_BLOCK) void primary_hits_kernel_f64_mx(DevScene<double> sc, DevCamera<double> cam, DevPart part, uint32_t* __restrict__ out_id,
+                                                                         double* __restrict__ out_t) {
+    __shared__ MxLds64 L;
+    const bool res = L.fill(sc);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (res) {
+        TracerF64Mx<true> tr{sc, L, w};
+        primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_WAVES_PER_BLOCK + w, lane, out_id, out_t);
+    } else {
+        TracerF64Mx<false> tr{sc, L, w};
+        primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_WAVES_PER_BLOCK + w, lane, out_id, out_t);
+    }
 }
 __global__ __launch_bounds__(MIRT_F32_BLOCK) void primary_hits_kernel_f32(DevScene<float> sc, DevCamera<float> cam, DevPart part, uint32_t* __restrict__ out_id,
                                                                           float* __restrict__ out_t) {
@@ -1378,6 +1429,20 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel_f64(DevSc
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     TracerF64 tr{sc, lds_all[w]};
     render_body(tr, sc, cam, part, rp, partial, stats, lane);
+}
+/* parity mode with the broad phase on the matrix pipe: f32 filter, exact f64 narrow phase and shading */
+__global__ __launch_bounds__(MIRT_BLOCK, 2) void render_kernel_f64_mx(DevScene<double> sc, DevCamera<double> cam, DevPart part, RenderParams rp,
+                                                                      double* __restrict__ partial, DevStats* __restrict__ stats) {
+    __shared__ MxLds64 L;
+    const bool res = L.fill(sc);
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (res) {
+        TracerF64Mx<true> tr{sc, L, w};
+        render_body(tr, sc, cam, part, rp, partial, stats, lane);
+    } else {
+        TracerF64Mx<false> tr{sc, L, w};
+        render_body(tr, sc, cam, part, rp, partial, stats, lane);
+    }
 }
 /* MIRT_FLAG_BVH: latency-bound per-lane traversal, small blocks, as many waves as the registers allow */
 __global__ __launch_bounds__(MIRT_BLOCK) void render_kernel_f32_bvh(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,

@@ -199,3 +199,66 @@ def test_inside_a_sphere_and_degenerate_inputs(oracle):
     sc.build_bvh()
     ids = _maps(oracle, sc, Camera.build((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), None, 96, 1.0, 0, None, None, None, 10))
     assert 0 in ids and 3 in ids
+
+
+# ---- the f64 parity mode with the (f32) broad phase on the matrix pipe ---------------------------------------------------
+def _maps64(oracle, sc, cam, expect="f64-matrix", check_oracle=True):
+    assert cam.closest_hit_kind(sc, precision=abi.F64) == expect
+    assert cam.closest_hit_kind(sc, precision=abi.F64, accel="valu") == "f64"
+    ids, t = cam.primary_hits(sc, precision=abi.F64)
+    v_ids, v_t = cam.primary_hits(sc, precision=abi.F64, accel="valu")
+    assert np.array_equal(ids, v_ids) and np.array_equal(t.view(np.uint64), v_t.view(np.uint64))
+    if check_oracle:
+        o_ids, o_t = oracle.primary_hits(sc.flat, cam.pod, abi.F64)
+        assert np.array_equal(ids, o_ids) and np.array_equal(t.view(np.uint64), o_t.view(np.uint64))
+    return ids
+
+
+@pytest.mark.parametrize("width", [400, 1920])
+def test_f64_matrix_maps_bouncing_balls(oracle, width):
+    ids = _maps64(oracle, presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(width, 0, 50), check_oracle=width <= 400)
+    assert (ids != abi.MISS_ID).any() and (ids == abi.MISS_ID).any()
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-3, 3e4])
+def test_f64_matrix_maps_are_scale_free(oracle, scale):
+    sc, cam = _moving_mix(scale)
+    assert len(np.unique(_maps64(oracle, sc, cam))) > 50
+
+
+def test_f64_matrix_maps_with_centres_that_f32_cannot_hold(oracle):
+    """Centres and radii with bits below f32's last place: the balls behind the operands are built around the f64 spheres
+    (the f32-rounded centre plus the rounding distance), so silhouettes that differ between the two precisions stay exact."""
+    rng = np.random.default_rng(21)
+    sc = Scene()
+    m = Lambertian.new((0.5, 0.5, 0.5), 1.0)
+    for k in range(300):
+        c = rng.uniform(-40, 40, 3) + rng.uniform(-1e-7, 1e-7, 3)
+        r = float(rng.uniform(0.3, 1.5)) * (1.0 + 1e-9 * k)
+        if k % 4 == 0:
+            sc.add(Sphere.new(r, tuple(c), tuple(c + rng.uniform(-1, 1, 3)), m))
+        else:
+            sc.add(Sphere.new_static(r, tuple(c), m))
+    sc.build_bvh()
+    cam = Camera.build((90.0 + 1e-9, 30.0, 20.0), (0.0, 0.0, 0.0), None, 300, 1.0, 0, 0.8, None, None, 5)
+    assert len(np.unique(_maps64(oracle, sc, cam))) > 100
+
+
+def test_f64_matrix_streams_large_scenes(oracle):
+    sc = presets.stress_scene(1500, seed=3)
+    assert len(np.unique(_maps64(oracle, sc, presets.stress_camera(128, 0, 50)))) > 100
+
+
+@pytest.mark.parametrize("name", ["balls", "mix"])
+def test_f64_render_is_bit_identical_on_both_broad_phases(name):
+    if name == "balls":
+        sc, cam = presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(128, 4, 50)
+    else:
+        sc, _ = _moving_mix(1.0)
+        cam = Camera.build((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), None, 96, 16.0 / 9.0, 4, 0.35, 10.0, 0.02, 30)
+    assert cam.closest_hit_kind(sc, precision=abi.F64) == "f64-matrix"
+    a, a8 = cam.render_arrays(sc, precision=abi.F64, seed=4)
+    seg = cam.last_stats["segments"]
+    b, b8 = cam.render_arrays(sc, precision=abi.F64, seed=4, accel="valu")
+    assert cam.last_stats["segments"] == seg
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64)) and np.array_equal(a8, b8)

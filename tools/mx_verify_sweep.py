@@ -10,6 +10,7 @@ from raytracer_amd import abi
 from raytracer_amd.api import Camera, Dielectric, Lambertian, Metal, Scene, Sphere
 
 os.environ["MIRT_BROAD"] = "matrix"
+PREC = abi.F64 if os.environ.get("MIRT_SWEEP_PRECISION") == "64" else abi.F32  # the f64 kernels use the same filter on balls around the f64 spheres
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 mats = [Lambertian.new((0.6, 0.6, 0.6), 1.0), Metal.new((0.9, 0.9, 0.9), None), Metal.new((0.8, 0.8, 0.8), 0.2), Dielectric.new(1.5)]
 n_matrix = 0
@@ -39,9 +40,9 @@ for case in range(40):
     d = d / np.linalg.norm(d)
     lookfrom = (off + d * dist) * scale
     cam = Camera.build(tuple(lookfrom), tuple(off * scale), None, 96, 1.0, 4, float(rng.uniform(0.3, 1.2)), float(dist * scale), float(rng.uniform(0.0, 0.05)), 50)
-    kind = cam.closest_hit_kind(sc, precision=abi.F32)
-    n_matrix += kind == "matrix"
+    kind = cam.closest_hit_kind(sc, precision=PREC)
+    n_matrix += kind in ("matrix", "f64-matrix")
     print(f"case {case}: n={n} scale=2^{int(np.log2(scale))} ext={ext:.1f} big={big} kind={kind}", flush=True)
-    cam.render_arrays(sc, precision=abi.F32, seed=case)
-    cam.primary_hits(sc, precision=abi.F32)
+    cam.render_arrays(sc, precision=PREC, seed=case)
+    cam.primary_hits(sc, precision=PREC)
 print("cases on the matrix pipe:", n_matrix)
