@@ -237,6 +237,20 @@ def main():
                 ms2.append(st2.kernel_ms)
             out["accel_bvh"] = {"value": round(st2.segments / (min(ms2) * 1e-3) / 1e6, 3), "unit": "Mrays/s", "kernel_ms": round(min(ms2), 3),
                                 "note": "same frame, closest hit through the bounding-volume tree instead of the brute-force tile loop; same image"}
+        if world == 1 and args.precision == 32 and not args.no_extras:
+            # not the metric: the same frame in the f64 parity mode (the reference's arithmetic operation for operation)
+            band64 = torch.zeros((rows0, W, 3), dtype=torch.float64, device="cuda")
+            o4 = cam.opts(precision=64, seed=args.seed, strip_rows=S, part_index=0, part_count=1, flags=abi.FLAG_COMPACT_ROWS)
+            k4 = lib.mirt_closest_hit_kind(ds.handle, C.byref(cam.pod), C.byref(o4))
+            st4 = abi.MirtStats()
+            ms4 = []
+            for _ in range(2):
+                abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(o4), band64.data_ptr(), band8.data_ptr(), stream, C.byref(st4)))
+                ms4.append(st4.kernel_ms)
+            out["f64_parity_mode"] = {"value": round(st4.segments / (min(ms4) * 1e-3) / 1e6, 3), "unit": "Mrays/s", "kernel_ms": round(min(ms4), 3),
+                                      "kernel": "render_kernel_f64_mx" if k4 == 4 else "render_kernel_f64<2>",
+                                      "note": "same scene and camera in binary64; its own RNG dimension layout, so a different (equally valid) image"}
+            del band64
         if world == 1 and not args.no_cpu_baseline:
             base, mt = cpu_baseline(scene, cam, args.seed, args.cpu_seconds)
             out["cpu_baseline"] = base
