@@ -1431,7 +1431,7 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel_f64(DevSc
     render_body(tr, sc, cam, part, rp, partial, stats, lane);
 }
 /* parity mode with the broad phase on the matrix pipe: f32 filter, exact f64 narrow phase and shading */
-__global__ __launch_bounds__(MIRT_BLOCK, 2) void render_kernel_f64_mx(DevScene<double> sc, DevCamera<double> cam, DevPart part, RenderParams rp,
+__global__ __launch_bounds__(MIRT_BLOCK, 3) void render_kernel_f64_mx(DevScene<double> sc, DevCamera<double> cam, DevPart part, RenderParams rp,
                                                                       double* __restrict__ partial, DevStats* __restrict__ stats) {
     __shared__ MxLds64 L;
     const bool res = L.fill(sc);
