@@ -467,16 +467,25 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
 typedef _Float16 mirt_h8 __attribute__((ext_vector_type(8)));
 typedef float mirt_f16v __attribute__((ext_vector_type(16)));
 typedef uint32_t mirt_u4 __attribute__((ext_vector_type(4)));
+#define MIRT_MX_LDS_MATS 640u
 struct MxLds {
     static constexpr bool GEOM_LDS = true; /* exact records and material ids of a resident scene are here as well */
     uint4 SM[MIRT_LDS_RECORDS * 2]; /* 64 x 16 B per tile of 32 spheres */
     float4 A[MIRT_LDS_RECORDS];
     float4 B[MIRT_LDS_RECORDS];
     uint16_t mat[MIRT_LDS_RECORDS];
-    uint32_t ent[MIRT_F32_WAVES][MIRT_ENT_CAP][MIRT_WAVE];
+    static constexpr uint32_t LDS_ENT_CAP = 12;
+    uint32_t ent[MIRT_F32_WAVES][LDS_ENT_CAP][MIRT_WAVE];
+    DevMaterial<float> mats[MIRT_MX_LDS_MATS]; /* the scene's materials when they fit: the shading of a segment starts with this record */
     /* all threads of the block; true when the scene is resident (larger scenes read their operands through L1/L2) */
     __device__ inline bool fill(const DevScene<float>& sc) {
         const bool res = sc.n <= MIRT_LDS_RECORDS && sc.n_materials <= 0x10000u;
+        if (sc.n_materials <= MIRT_MX_LDS_MATS) {
+            const uint32_t nd = sc.n_materials * (uint32_t)(sizeof(DevMaterial<float>) / 4);
+            const uint32_t* src = (const uint32_t*)sc.mats;
+            uint32_t* dst = (uint32_t*)mats;
+            for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+        }
         if (res) {
             const uint32_t ntiles = (sc.n + 31) / 32;
             for (uint32_t i = threadIdx.x; i < ntiles * 64; i += blockDim.x) SM[i] = sc.SM[i];
@@ -493,6 +502,7 @@ struct MxLds {
 /* f64 kernels (256-thread blocks): only the operands and the entry lists; the exact f64 records come through L2 */
 struct MxLds64 {
     static constexpr bool GEOM_LDS = false;
+    static constexpr uint32_t LDS_ENT_CAP = MIRT_ENT_CAP;
     uint4 SM[MIRT_LDS_RECORDS * 2];
     uint32_t ent[MIRT_WAVES_PER_BLOCK][MIRT_ENT_CAP][MIRT_WAVE];
     __device__ inline bool fill(const DevScene<double>& sc) {
@@ -618,12 +628,12 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
                 if (active && dd_ >= (R)0.0 && ((word_ >> (15 - (k_ & 15u))) & 1u)) atomicAdd(sc.dbg, 1ull);
             }
 #endif
-            /* unconditional writes, conditional advance (cnt <= MIRT_ENT_CAP - 2 here: a nearly full list flushes below) */
+            /* unconditional writes, conditional advance (cnt <= LDS_ENT_CAP - 2 here: a nearly full list flushes below) */
             ent[cnt][lane] = mx;
             cnt += ((mx & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
             ent[cnt][lane] = my;
             cnt += ((my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
-            flush = __ballot(cnt > MIRT_ENT_CAP - 2) != 0ull; /* no room for another tile */
+            flush = __ballot(cnt > LDS::LDS_ENT_CAP - 2) != 0ull; /* no room for another tile */
         }
         pt.stamp(PH_BROAD);
         /* ---- narrow phase: as in trace_cons ---- */
@@ -903,6 +913,7 @@ struct TracerF64 {
     }
     __device__ inline Hit<double> hit(const Closest<double>& c, const RayT<double>& ray) const { return make_hit(sc, GeomGlobal<double>{sc}, c, ray); }
     __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }
+    __device__ inline const DevMaterial<double>& material_record(uint32_t idx) const { return sc.mats[material(idx)]; }
 };
 template <bool RES> struct TracerF32 {
     typedef float Real;
@@ -918,6 +929,7 @@ template <bool RES> struct TracerF32 {
         return make_hit(sc, GeomGlobal<float>{sc}, c, ray);
     }
     __device__ inline uint32_t material(uint32_t idx) const { return RES ? (uint32_t)L.mat[idx] : sc.material[idx]; }
+    __device__ inline const DevMaterial<float>& material_record(uint32_t idx) const { return sc.mats[material(idx)]; }
 };
 
 template <bool RES> struct TracerF32Mx {
@@ -941,6 +953,12 @@ template <bool RES> struct TracerF32Mx {
         return make_hit(sc, GeomGlobal<float>{sc}, c, ray);
     }
     __device__ inline uint32_t material(uint32_t idx) const { return RES ? (uint32_t)L.mat[idx] : sc.material[idx]; }
+    /* by value: the record may come from the LDS copy or from HBM/L2 (two address spaces) */
+    __device__ inline DevMaterial<float> material_record(uint32_t idx) const {
+        const uint32_t m = material(idx);
+        if (sc.n_materials <= MIRT_MX_LDS_MATS) return L.mats[m];
+        return sc.mats[m];
+    }
 };
 
 template <bool RES> struct TracerF64Mx {
@@ -954,6 +972,7 @@ template <bool RES> struct TracerF64Mx {
     }
     __device__ inline Hit<double> hit(const Closest<double>& c, const RayT<double>& ray) const { return make_hit(sc, GeomGlobal<double>{sc}, c, ray); }
     __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }
+    __device__ inline const DevMaterial<double>& material_record(uint32_t idx) const { return sc.mats[material(idx)]; }
 };
 
 template <class Store, bool DYN> struct TracerF32Bvh {
@@ -971,6 +990,7 @@ template <class Store, bool DYN> struct TracerF32Bvh {
     }
     __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const { return make_hit(sc, store.geom(), c, ray); }
     __device__ inline uint32_t material(uint32_t idx) const { return store.geom().material(idx); }
+    __device__ inline const DevMaterial<float>& material_record(uint32_t idx) const { return sc.mats[material(idx)]; }
 };
 
 /* ---- textures: scene/texture.rs ----------------------------------------------------------------- */
@@ -1032,9 +1052,8 @@ template <class R> __device__ inline V3<R> refract(V3<R> uv, V3<R> n, R e) { /* 
  * The bounce's Philox block is evaluated ONCE, before the material switch: a wave usually holds lanes of all three
  * materials, and divergent branches that each called the generator would run it up to three times. */
 template <class R>
-__device__ inline bool scatter(const DevScene<R>& sc, uint32_t mat, const RayT<R>& rin, const Hit<R>& hit, const Draws<R>& dr, V3<R>& att,
+__device__ inline bool scatter(const DevScene<R>& sc, const DevMaterial<R>& m, const RayT<R>& rin, const Hit<R>& hit, const Draws<R>& dr, V3<R>& att,
                                RayT<R>& out) {
-    const DevMaterial<R>& m = sc.mats[mat];
     R ua, ub, uc, ud; /* dims 0..3 of this bounce */
     dr.dims0123(ua, ub, uc, ud);
     if (m.kind == MIRT_MAT_LAMBERTIAN) { /* material.rs:59-84; dims: 0 = absorb test, 1..3 = vector */
@@ -1373,7 +1392,7 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 Draws<R> dr{pixel, sample, bounce, rp.k0, rp.k1};
                 V3<R> att;
                 RayT<R> nxt;
-                if (scatter(sc, tr.material(best.idx), ray, hit, dr, att, nxt)) {
+                if (scatter(sc, tr.material_record(best.idx), ray, hit, dr, att, nxt)) {
                     thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
                     ray = nxt;
                     --depth_left;
