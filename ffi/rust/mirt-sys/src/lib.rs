@@ -152,6 +152,9 @@ extern "C" {
     pub fn mirt_quantize_device(d_linear: *const c_void, precision: u32, n: usize, d_out: *mut u8, stream: *mut c_void, nan_count: *mut u64) -> c_int;
     pub fn mirt_deinterleave_device(d_bands: *const c_void, band_stride_bytes: usize, part_count: u32, strip_rows: u32, width: u32, height: u32, elem_bytes: u32, d_frame: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn mirt_part_rows(height: u32, strip_rows: u32, part_index: u32, part_count: u32) -> u32;
+    pub fn mirt_render_pass_device(scene: *const mirt_scene, cam: *const mirt_camera, opts: *const mirt_opts, first_sample: u32, sample_count: u32, d_accum: *mut c_void, d_rgb_linear: *mut c_void, d_rgb8: *mut u8, stream: *mut c_void, stats: *mut mirt_stats) -> c_int;
+    pub fn mirt_render_pass(scene: *const mirt_scene, cam: *const mirt_camera, opts: *const mirt_opts, first_sample: u32, sample_count: u32, accum: *mut c_void, rgb_linear: *mut c_void, rgb8: *mut u8, stats: *mut mirt_stats) -> c_int;
+    pub fn mirt_pass_granularity(cam: *const mirt_camera, opts: *const mirt_opts) -> u32;
     pub fn mirt_closest_hit_kind(scene: *const mirt_scene, cam: *const mirt_camera, opts: *const mirt_opts) -> c_int;
     pub fn mirt_philox4x32_10(ctr: *const u32, key: *const u32, out: *mut u32);
 }

@@ -193,6 +193,24 @@ int mirt_primary_hits_device(const mirt_scene* scene, const mirt_camera* cam, co
 int mirt_quantize_device(const void* d_linear, uint32_t precision, size_t n, uint8_t* d_out,
                          void* stream, uint64_t* nan_count);
 
+/* Progressive rendering / checkpointing (the reference renders a frame in one go): add samples
+ * [first_sample, first_sample + sample_count) of every pixel of the image `cam` describes (samples_per_pixel = the FINAL
+ * count: it fixes the sample set and the work decomposition) to `accum` - the running radiance SUMS, precision-sized RGB
+ * in the layout of the linear output, caller-owned, read when first_sample > 0 and always written - and, where the
+ * pointers are not NULL, write the image so far: the sums divided by the samples accumulated, and its quantised bytes.
+ * Pass boundaries must be multiples of mirt_pass_granularity() (the last pass ends at samples_per_pixel).  After the
+ * last pass the image equals mirt_render's bit for bit, however the range was cut and whether or not the sums went
+ * through a checkpoint file in between. */
+int mirt_render_pass_device(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
+                            uint32_t first_sample, uint32_t sample_count, void* d_accum,
+                            void* d_rgb_linear, uint8_t* d_rgb8, void* stream, mirt_stats* stats);
+/* The same with host buffers (full frames only); `accum` is required. */
+int mirt_render_pass(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
+                     uint32_t first_sample, uint32_t sample_count, void* accum,
+                     void* rgb_linear, uint8_t* rgb8, mirt_stats* stats);
+/* Samples per work item for this image and partition (1, 2, 4, ...): the unit of pass boundaries.  0 = no anti-aliasing. */
+uint32_t mirt_pass_granularity(const mirt_camera* cam, const mirt_opts* opts);
+
 /* K4: scatter `part_count` compact bands (as gathered with RCCL, band r at
  * d_bands + r * band_stride_bytes, each holding that part's rows packed in row order) into the
  * full frame.  elem_bytes = bytes per pixel (e.g. 12 for f32 RGB, 3 for rgb8). */

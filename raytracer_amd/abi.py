@@ -117,6 +117,9 @@ EXPORTS = [
     "mirt_deinterleave_device",
     "mirt_part_rows",
     "mirt_closest_hit_kind",
+    "mirt_render_pass_device",
+    "mirt_render_pass",
+    "mirt_pass_granularity",
     "mirt_philox4x32_10",
 ]
 
@@ -166,6 +169,10 @@ def load():
     lib.mirt_deinterleave_device.argtypes = [vp, sz, u32, u32, u32, u32, u32, vp, vp]
     lib.mirt_part_rows.argtypes = [u32, u32, u32, u32]
     lib.mirt_part_rows.restype = u32
+    lib.mirt_render_pass_device.argtypes = [vp, P(MirtCamera), P(MirtOpts), u32, u32, vp, vp, vp, vp, P(MirtStats)]
+    lib.mirt_render_pass.argtypes = [vp, P(MirtCamera), P(MirtOpts), u32, u32, vp, vp, vp, P(MirtStats)]
+    lib.mirt_pass_granularity.argtypes = [P(MirtCamera), P(MirtOpts)]
+    lib.mirt_pass_granularity.restype = u32
     lib.mirt_closest_hit_kind.argtypes = [vp, P(MirtCamera), P(MirtOpts)]
     lib.mirt_closest_hit_kind.restype = C.c_int
     lib.mirt_philox4x32_10.argtypes = [P(u32), P(u32), P(u32)]

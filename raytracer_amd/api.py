@@ -413,6 +413,34 @@ class Camera:
         self.last_stats = st.asdict()
         return lin, rgb8
 
+    def pass_granularity(self, precision=None) -> int:
+        """Samples per work item for this image (mirt_pass_granularity): progressive passes begin and end on multiples of it."""
+        o = self.opts(precision=self.precision if precision is None else precision)
+        return int(abi.load().mirt_pass_granularity(C.byref(self.pod), C.byref(o)))
+
+    def render_pass(self, scene: Scene, first: int, count: int, accum: np.ndarray, precision=None, seed=None, want_linear=True, want_rgb8=True, accel=None):
+        """Progressive rendering / checkpointing (mirt_render_pass): add samples [first, first + count) of every pixel to
+        `accum` ((H,W,3) radiance sums, in place; save it and `first + count` to checkpoint) and return the image so far as
+        render_arrays would.  After the last pass the image equals render_arrays' bit for bit."""
+        ds = scene.device_scene(self.device)
+        prec = self.precision if precision is None else precision
+        H, W = self.height, self.width
+        real = np.float64 if prec == abi.F64 else np.float32
+        if accum.shape != (H, W, 3) or accum.dtype != real or not accum.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"accum must be a contiguous ({H},{W},3) {np.dtype(real).name} array")
+        lin = np.empty((H, W, 3), dtype=real) if want_linear else None
+        rgb8 = np.empty((H, W, 3), dtype=np.uint8) if want_rgb8 else None
+        st = abi.MirtStats()
+        o = self.opts(precision=prec, seed=seed, flags=_accel_flags(accel))
+        abi.check(
+            abi.load().mirt_render_pass(
+                ds.handle, C.byref(self.pod), C.byref(o), first, count, accum.ctypes.data,
+                None if lin is None else lin.ctypes.data, None if rgb8 is None else rgb8.ctypes.data, C.byref(st),
+            )
+        )
+        self.last_stats = st.asdict()
+        return lin, rgb8
+
     def primary_hits(self, scene: Scene, precision=None, accel=None):
         """Hit-id / t map of the deterministic branch (camera.rs:247-254)."""
         ds = scene.device_scene(self.device)

@@ -491,7 +491,8 @@ static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStre
 
 template <class R>
 static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mirt_camera* cam, const DevPart& part, uint64_t seed, void* d_lin,
-                         uint8_t* d_rgb8, hipStream_t st, bool use_bvh, bool mx) {
+                         uint8_t* d_rgb8, hipStream_t st, bool use_bvh, bool mx, uint32_t first_sample = 0, uint32_t sample_count = 0xFFFFFFFFu,
+                         void* d_accum = nullptr) {
     /* closest-hit front end: 0 = brute force, VALU broad phase; 1 = tree in HBM/L2; 2 = tree, records and spheres resident in
      * LDS; 3 = brute force, broad phase on the matrix pipe */
     const int bvh = mx ? 3 : !use_bvh ? 0
@@ -503,6 +504,21 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     RenderParams rp;
     rp.nsamples = cam->samples_per_pixel ? cam->samples_per_pixel : 1u;
     choose_chunks(n_pixels, rp.nsamples, sizeof(R), &rp.chunk, &rp.chunks);
+    /* a progressive pass renders whole chunks [first / Q, (first + count) / Q) of the same decomposition the one-call render uses */
+    rp.chunk_first = 0;
+    rp.norm_samples = rp.nsamples;
+    if (sample_count != 0xFFFFFFFFu) {
+        if (!cam->samples_per_pixel) return fail(MIRT_ERR_INVALID, "progressive passes need anti-aliasing samples (samples_per_pixel > 0)");
+        const uint64_t last = (uint64_t)first_sample + sample_count;
+        if (sample_count == 0 || last > rp.nsamples) return fail(MIRT_ERR_INVALID, "pass: sample range outside [0, samples_per_pixel)");
+        if (first_sample % rp.chunk != 0 || (last != rp.nsamples && last % rp.chunk != 0))
+            return fail(MIRT_ERR_INVALID, "pass: boundaries must be multiples of the work-item size (" + std::to_string(rp.chunk) +
+                                              " samples for this image; see mirt_pass_granularity)");
+        if (first_sample != 0 && !d_accum) return fail(MIRT_ERR_INVALID, "pass: a later pass needs the accumulation buffer of the earlier ones");
+        rp.chunk_first = first_sample / rp.chunk;
+        rp.chunks = (uint32_t)((last + rp.chunk - 1) / rp.chunk) - rp.chunk_first;
+        rp.norm_samples = (uint32_t)last;
+    }
     /* queue order: passes of G = 2^g_shift chunks (render_body).  Long launches (>= 128 items per lane of the chip) keep all
      * chunks of a pixel together, short ones - an 8-GPU band of the bench frame has 63 - use passes of 4 (measured:
      * profiles/r01_microbench.txt); MIRT_GROUP_CHUNKS is the tuning knob */
@@ -550,7 +566,7 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     }
     uint32_t rgrid = (uint32_t)((n_pixels + 255) / 256);
     hipLaunchKernelGGL((resolve_kernel<R>), dim3(rgrid), dim3(256), 0, st, (const R*)s->partial, dev_camera<R>(cam), part, rp, (uint32_t)n_pixels,
-                       (R*)d_lin, d_rgb8, s->stats);
+                       (R*)d_lin, d_rgb8, s->stats, (R*)d_accum);
     HIP_TRY(hipGetLastError());
     return MIRT_OK;
 }
@@ -727,8 +743,27 @@ int mirt_primary_hits_device(const mirt_scene* s, const mirt_camera* cam, const 
                                     : launch_primary(s, s->f32, cam, part, d_id, d_t, st, (o->flags & MIRT_FLAG_BVH) != 0, mx);
 }
 
+static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t first_sample, uint32_t sample_count, void* d_accum,
+                       void* d_lin, uint8_t* d_rgb8, void* stream, mirt_stats* stats);
 int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, void* d_lin, uint8_t* d_rgb8, void* stream,
                        mirt_stats* stats) {
+    return render_impl(s, cam, o, 0, 0xFFFFFFFFu, nullptr, d_lin, d_rgb8, stream, stats);
+}
+int mirt_render_pass_device(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t first_sample, uint32_t sample_count,
+                            void* d_accum, void* d_lin, uint8_t* d_rgb8, void* stream, mirt_stats* stats) {
+    if (sample_count == 0xFFFFFFFFu) return fail(MIRT_ERR_INVALID, "pass: sample_count out of range");
+    return render_impl(s, cam, o, first_sample, sample_count, d_accum, d_lin, d_rgb8, stream, stats);
+}
+uint32_t mirt_pass_granularity(const mirt_camera* cam, const mirt_opts* o) {
+    if (!cam || !o || !cam->samples_per_pixel) return 0;
+    DevPart part;
+    if (make_part(cam, o, &part)) return 0;
+    uint32_t chunk = 1, chunks = 1;
+    choose_chunks((uint64_t)cam->img_width * part.local_rows, cam->samples_per_pixel, o->precision == MIRT_F64 ? 8 : 4, &chunk, &chunks);
+    return chunk;
+}
+static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t first_sample, uint32_t sample_count, void* d_accum,
+                       void* d_lin, uint8_t* d_rgb8, void* stream, mirt_stats* stats) {
     int rc = check_common(s, cam, o);
     if (rc) return rc;
     DevPart part;
@@ -745,8 +780,9 @@ int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_o
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    rc = o->precision == MIRT_F64 ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st, false, mx)
-                                  : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0, mx);
+    rc = o->precision == MIRT_F64
+             ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st, false, mx, first_sample, sample_count, d_accum)
+             : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0, mx, first_sample, sample_count, d_accum);
     if (stats) {
         if (!rc) {
             hipError_t e = hipEventRecord(e1, st);
@@ -845,6 +881,37 @@ int mirt_render(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o,
     if (!rc && lin && hipMemcpy(lin, d_lin, n * rsz, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
     if (!rc && rgb8 && hipMemcpy(rgb8, d_rgb8, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
     if (!rc && stats) *stats = local;
+    (void)hipFree(d_lin);
+    (void)hipFree(d_rgb8);
+    if (!rc && rgb8 && local.nan_pixels) return fail(MIRT_ERR_NAN, "a NaN reached the quantiser (the reference panics: rgb.rs:33)");
+    return rc;
+}
+
+int mirt_render_pass(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t first_sample, uint32_t sample_count, void* accum,
+                     void* lin, uint8_t* rgb8, mirt_stats* stats) {
+    int rc = check_common(s, cam, o);
+    if (rc) return rc;
+    if (o->flags & MIRT_FLAG_COMPACT_ROWS) return fail(MIRT_ERR_INVALID, "host-buffer calls write full frames; use the _device entry point for compact bands");
+    if (!accum) return fail(MIRT_ERR_INVALID, "pass: the accumulation buffer is required");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t n = (size_t)cam->img_width * cam->img_height * 3, rsz = o->precision == MIRT_F64 ? 8 : 4;
+    void *d_acc = nullptr, *d_lin = nullptr;
+    uint8_t* d_rgb8 = nullptr;
+    if (hipMalloc(&d_acc, n * rsz) != hipSuccess) return fail(MIRT_ERR_NOMEM, "hipMalloc failed");
+    if (lin && hipMalloc(&d_lin, n * rsz) != hipSuccess) { (void)hipFree(d_acc); return fail(MIRT_ERR_NOMEM, "hipMalloc failed"); }
+    if (rgb8 && hipMalloc((void**)&d_rgb8, n) != hipSuccess) { (void)hipFree(d_acc); (void)hipFree(d_lin); return fail(MIRT_ERR_NOMEM, "hipMalloc failed"); }
+    rc = MIRT_OK;
+    /* rows outside the part stay as the caller's accumulation has them */
+    if (hipMemcpy(d_acc, accum, n * rsz, hipMemcpyHostToDevice) != hipSuccess) rc = fail(MIRT_ERR_HIP, "upload of the accumulation buffer failed");
+    if (!rc && d_lin && hipMemset(d_lin, 0, n * rsz) != hipSuccess) rc = fail(MIRT_ERR_HIP, "hipMemset failed");
+    if (!rc && d_rgb8 && hipMemset(d_rgb8, 0, n) != hipSuccess) rc = fail(MIRT_ERR_HIP, "hipMemset failed");
+    mirt_stats local;
+    if (!rc) rc = mirt_render_pass_device(s, cam, o, first_sample, sample_count, d_acc, d_lin, d_rgb8, nullptr, &local);
+    if (!rc && hipMemcpy(accum, d_acc, n * rsz, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
+    if (!rc && lin && hipMemcpy(lin, d_lin, n * rsz, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
+    if (!rc && rgb8 && hipMemcpy(rgb8, d_rgb8, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
+    if (!rc && stats) *stats = local;
+    (void)hipFree(d_acc);
     (void)hipFree(d_lin);
     (void)hipFree(d_rgb8);
     if (!rc && rgb8 && local.nan_pixels) return fail(MIRT_ERR_NAN, "a NaN reached the quantiser (the reference panics: rgb.rs:33)");

@@ -1244,6 +1244,8 @@ struct RenderParams {
     uint32_t n_items;    /* band pixels * chunks_per_pixel */
     uint32_t chunks;     /* chunks per pixel */
     uint32_t chunk;      /* samples per chunk */
+    uint32_t chunk_first; /* first chunk of this call (progressive passes: mirt_render_pass_device), 0 otherwise */
+    uint32_t norm_samples; /* samples per pixel accumulated once this call is done: the divisor of the normalised output */
     uint32_t nsamples;   /* samples per pixel (1 when anti-aliasing is off) */
     uint32_t k0, k1;     /* RNG key */
     uint32_t tail_items; /* queue tail served in batches of one item per lane (guided self-scheduling) */
@@ -1333,7 +1335,7 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                     gy = (ls * part.part_count + part.part_index) * part.strip_rows + (ly - ls * part.strip_rows);
                 }
                 pixel = gy * cam.W + lx; /* RNG key: the global pixel, independent of the partition */
-                sample = ch * rp.chunk;
+                sample = (rp.chunk_first + ch) * rp.chunk;
                 s_end = sample + rp.chunk < rp.nsamples ? sample + rp.chunk : rp.nsamples;
                 acc = {(R)0.0, (R)0.0, (R)0.0};
                 has_work = ch < rp.chunks;
@@ -1514,10 +1516,16 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
  *      (rgb.rs:20-36).  One thread per band pixel. */
 template <class R>
 __global__ void resolve_kernel(const R* __restrict__ partial, DevCamera<R> cam, DevPart part, RenderParams rp, uint32_t n_pixels,
-                               R* __restrict__ out_lin, uint8_t* __restrict__ out_rgb8, DevStats* __restrict__ stats) {
+                               R* __restrict__ out_lin, uint8_t* __restrict__ out_rgb8, DevStats* __restrict__ stats, R* accum) {
     uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
     if (pl >= n_pixels) return;
+    const uint32_t ly = pl / cam.W, lx = pl - ly * cam.W;
+    const uint32_t row = part.compact ? ly : part_global_row(part, ly);
+    const size_t o = ((size_t)row * cam.W + lx) * 3;
+    /* progressive passes carry the running sum of the earlier chunks in `accum` (same layout as the output) and go on adding
+     * in chunk order, so the sum after the last pass is the one-call sum bit for bit */
     V3<R> acc = {(R)0.0, (R)0.0, (R)0.0};
+    if (accum && rp.chunk_first != 0u) acc = {accum[o], accum[o + 1], accum[o + 2]};
     /* queue order (render_body): [pass][pixel][chunk within the pass]; summed in chunk order whatever the pass size */
     const uint32_t G = 1u << rp.g_shift;
     const R* p = partial + ((size_t)pl << rp.g_shift) * 3;
@@ -1525,10 +1533,12 @@ __global__ void resolve_kernel(const R* __restrict__ partial, DevCamera<R> cam, 
         const uint32_t n = rp.chunks - c0 < G ? rp.chunks - c0 : G;
         for (uint32_t k = 0; k < n; ++k) acc = acc + V3<R>{p[3 * k], p[3 * k + 1], p[3 * k + 2]};
     }
-    if (cam.spp > 0) acc = acc * ((R)1.0 / (R)cam.spp); /* samples_scale, camera.rs:50,246 */
-    uint32_t ly = pl / cam.W, lx = pl - ly * cam.W;
-    uint32_t row = part.compact ? ly : part_global_row(part, ly);
-    size_t o = ((size_t)row * cam.W + lx) * 3;
+    if (accum) {
+        accum[o] = acc.x;
+        accum[o + 1] = acc.y;
+        accum[o + 2] = acc.z;
+    }
+    if (cam.spp > 0) acc = acc * ((R)1.0 / (R)rp.norm_samples); /* samples_scale, camera.rs:50,246 (norm_samples == spp unless this is an early pass) */
     if (out_lin) {
         out_lin[o] = acc.x;
         out_lin[o + 1] = acc.y;

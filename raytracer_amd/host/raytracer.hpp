@@ -329,6 +329,50 @@ class Camera {
         return px;
     }
 
+    /* Progressive rendering / checkpointing (no counterpart in the reference).  `accum` holds the running
+     * radiance sums (W*H*3 floats or doubles, by `precision`) and `done` the samples in them; render_more adds up to
+     * `count` samples per pixel (in whole work items) and returns the quantised image so far.  After the last sample the
+     * image equals render_rgb8's, bit for bit. */
+    struct Progress {
+        std::vector<unsigned char> accum; /* raw bytes of the sums: what a checkpoint stores */
+        uint32_t done = 0;
+    };
+    std::vector<uint8_t> render_more(const Scene& scene, Progress& pr, uint32_t count) {
+        const size_t n = (size_t)pod.img_width * pod.img_height * 3, rsz = precision == MIRT_F64 ? 8 : 4;
+        mirt_opts o{};
+        o.precision = precision;
+        o.seed = seed;
+        o.flags = (use_bvh ? MIRT_FLAG_BVH : 0u) | (valu_broad ? MIRT_FLAG_VALU_BROAD : 0u);
+        const uint32_t g = mirt_pass_granularity(&pod, &o), spp = pod.samples_per_pixel;
+        if (g == 0) throw RenderError("progressive rendering needs anti-aliasing samples");
+        if (pr.accum.size() != n * rsz) {
+            if (pr.done != 0) throw RenderError("checkpoint does not match the image size or precision");
+            pr.accum.assign(n * rsz, 0);
+        }
+        if (pr.done >= spp) throw RenderError("all samples are already rendered");
+        uint32_t last = pr.done + std::max(count, 1u);
+        last = last >= spp ? spp : std::max((last / g) * g, pr.done + g); /* whole work items; the last pass takes the rest */
+        last = std::min(last, spp);
+        std::vector<uint8_t> px(n);
+        check(mirt_render_pass(scene.handle(), &pod, &o, pr.done, last - pr.done, pr.accum.data(), nullptr, px.data(), &last_stats));
+        pr.done = last;
+        return px;
+    }
+
+    static void write_ppm(const std::vector<uint8_t>& px, uint32_t w, uint32_t h, std::ostream& out) {
+        out << "P3\n" << w << ' ' << h << "\n255\n";
+        if (!out) throw RenderError("WriteHeader");
+        std::string buf;
+        buf.reserve(px.size() * 4);
+        char line[16];
+        for (size_t i = 0; i < px.size(); i += 3) {
+            int n = std::snprintf(line, sizeof line, "%u %u %u\n", px[i], px[i + 1], px[i + 2]);
+            buf.append(line, (size_t)n);
+        }
+        out.write(buf.data(), (std::streamsize)buf.size());
+        if (!out) throw RenderError("WritePx");
+    }
+
     /* Camera::render (camera.rs:232-259): "P3\nW H\n255\n" then one "r g b\n" line per pixel. */
     void render(const Scene& scene, std::ostream& out) {
         out << "P3\n" << pod.img_width << ' ' << pod.img_height << "\n255\n";

@@ -358,3 +358,62 @@ def test_ppm_output_matches_oracle_bytes(oracle, scenes):
     cam.render(sc, out=buf)
     _, o_rgb8, _, _ = oracle.render(sc.flat, cam.pod, abi.F64, seed=0, threads=4)
     assert buf.getvalue() == b"P3\n64 36\n255\n" + ppm_body(o_rgb8)
+
+
+# ---- progressive passes / checkpointing ------------------------------------------------------------------
+@pytest.mark.parametrize("prec", [abi.F32, abi.F64])
+@pytest.mark.parametrize("accel", [None, "bvh", "valu"])
+def test_progressive_passes_equal_the_one_call_render(scenes, prec, accel):
+    """Any cut of the sample range into passes - also through a checkpoint (the sums saved and reloaded) - ends in the image
+    of the one-call render, bit for bit; intermediate images are the running means."""
+    if accel == "bvh" and prec == abi.F64:
+        pytest.skip("the tree is an f32-mode accelerator")
+    sc, cam = scenes["balls"], SCENES["balls"][1](96, 12)
+    cam.precision = prec
+    ref, ref8 = cam.render_arrays(sc, seed=5, accel=accel)
+    seg_ref = cam.last_stats["segments"]
+    g = cam.pass_granularity()
+    assert g >= 1 and 12 % g == 0
+    real = np.float64 if prec == abi.F64 else np.float32
+    for cuts in ([0, 12], [0, 4, 12], [0, 1 * g, 2 * g, 7 * g if 7 * g < 12 else 12, 12]):
+        cuts = sorted(set(cuts))
+        acc = np.full((cam.height, cam.width, 3), np.nan, dtype=real)  # the first pass must not read it
+        seg = 0
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            lin, rgb8 = cam.render_pass(sc, a, b - a, acc, seed=5, accel=accel)
+            seg += cam.last_stats["segments"]
+            acc = np.frombuffer(acc.tobytes(), dtype=real).reshape(acc.shape).copy()  # "checkpoint": through bytes and back
+            if b < 12:
+                assert np.allclose(lin, acc / b, rtol=1e-6, atol=0)
+        assert np.array_equal(lin.view(np.uint8), ref.view(np.uint8)) and np.array_equal(rgb8, ref8)
+        assert seg == seg_ref
+
+
+def test_progressive_pass_argument_errors(scenes):
+    sc, cam = scenes["balls"], SCENES["balls"][1](32, 8)
+    cam.precision = abi.F32
+    acc = np.zeros((cam.height, cam.width, 3), np.float32)
+    for first, count in ((0, 0), (0, 9), (8, 1), (4, 8)):
+        with pytest.raises(abi.MirtError):
+            cam.render_pass(sc, first, count, acc, seed=1)
+    cam0 = SCENES["balls"][1](32, 0)
+    cam0.precision = abi.F32
+    assert cam0.pass_granularity() == 0
+    with pytest.raises(abi.MirtError):
+        cam0.render_pass(sc, 0, 1, acc, seed=1)
+
+
+def test_progressive_passes_with_larger_work_items(scenes, monkeypatch):
+    """With several samples per work item (large images; here forced through the library's tuning knob) pass boundaries are
+    multiples of that size, and the result is still the one-call image."""
+    monkeypatch.setenv("MIRT_CHUNK", "4")
+    sc, cam = scenes["balls"], SCENES["balls"][1](64, 10)
+    cam.precision = abi.F32
+    assert cam.pass_granularity() == 4
+    ref, ref8 = cam.render_arrays(sc, seed=2)
+    acc = np.zeros((cam.height, cam.width, 3), np.float32)
+    with pytest.raises(abi.MirtError):
+        cam.render_pass(sc, 0, 6, acc, seed=2)
+    for a, b in ((0, 4), (4, 8), (8, 10)):
+        lin, rgb8 = cam.render_pass(sc, a, b - a, acc, seed=2)
+    assert np.array_equal(lin.view(np.uint8), ref.view(np.uint8)) and np.array_equal(rgb8, ref8)

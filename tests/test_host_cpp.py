@@ -194,3 +194,29 @@ def test_cli_presets_equal_python_presets(name, args):
 
     want = f"P3\n{cam.width} {cam.height}\n255\n".encode() + ppm_body(rgb8)
     assert r.stdout == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["32", "64"])
+def test_cli_progressive_passes_and_checkpoint_resume(tmp_path, prec):
+    """the frame rendered in passes - and across two runs through a checkpoint file - is the frame of one run."""
+    if not os.path.exists(os.path.join(ASSETS, "earthmap.ppm")):
+        import __graft_entry__
+
+        __graft_entry__.export_textures()
+    base = [_cli(), "render", "--scene", "bouncing_balls", "--width", "80", "--spp", "10", "--depth", "12", "--precision", prec, "--seed", "3",
+            "--textures", ASSETS]
+    one = subprocess.run(base, capture_output=True, timeout=120)
+    assert one.returncode == 0, one.stderr.decode()[-400:]
+    out = tmp_path / "p.ppm"
+    r = subprocess.run(base + ["--passes", "4", "--out", str(out)], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    assert out.read_bytes() == one.stdout and r.stderr.count(b"pass ") == 4
+    ck, out2 = tmp_path / "job.ck", tmp_path / "q.ppm"
+    r1 = subprocess.run(base + ["--passes", "3", "--checkpoint", str(ck), "--out", str(out2), "--stop-after", "1"], capture_output=True, timeout=120)
+    assert r1.returncode == 0 and ck.exists() and out2.read_bytes() != one.stdout  # a quarter of the samples so far
+    r2 = subprocess.run(base + ["--passes", "3", "--checkpoint", str(ck), "--out", str(out2)], capture_output=True, timeout=120)
+    assert r2.returncode == 0 and b"resuming" in r2.stderr, r2.stderr.decode()[-400:]
+    assert out2.read_bytes() == one.stdout
+    other = subprocess.run(base[:-4] + ["--seed", "4", "--textures", ASSETS, "--checkpoint", str(ck)], capture_output=True, timeout=120)
+    assert other.returncode == 1 and b"another job" in other.stderr
