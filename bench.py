@@ -211,6 +211,7 @@ def main():
             },
             "diagnostics": {
                 "segments_per_step": seg_all / args.steps,
+                "primary_samples_per_s": round(H * W * max(1, cam.pod.samples_per_pixel) * args.steps / elapsed, 1),
                 "lane_utilisation": round(seg_all / max(iters_all * 64.0, 1.0), 4),
                 "narrow_tests_per_segment": round(narrow_all / max(seg_all, 1.0), 3),
             },
