@@ -533,7 +533,9 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     rp.k1 = (uint32_t)(seed >> 32);
     rp.tail_items = 0;
     rp.n_pixels = (uint32_t)n_pixels;
-    rp.d_pg = make_fastdiv(rp.n_pixels << rp.g_shift);
+    rp.row_items = (uint32_t)((uint64_t)cam->img_width * (passes << rp.g_shift));
+    rp.d_row = make_fastdiv(rp.row_items);
+    rp.d_pg = make_fastdiv(cam->img_width << rp.g_shift);
     rp.d_W = make_fastdiv(cam->img_width);
     rp.d_strip = make_fastdiv(part.strip_rows);
     rp.keep_num = 0;

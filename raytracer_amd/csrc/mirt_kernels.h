@@ -1249,7 +1249,8 @@ struct RenderParams {
     uint32_t nsamples;   /* samples per pixel (1 when anti-aliasing is off) */
     uint32_t k0, k1;     /* RNG key */
     uint32_t tail_items; /* queue tail served in batches of one item per lane (guided self-scheduling) */
-    FastDiv d_pg, d_W, d_strip; /* divisions by n_pixels << g_shift, image width and strip height when an item is decoded */
+    FastDiv d_row, d_pg, d_W, d_strip; /* divisions by W * slots per pixel, W << g_shift, image width and strip height when an item is decoded */
+    uint32_t row_items;  /* queue slots per image row: W * (passes << g_shift) */
     uint32_t n_pixels;   /* band pixels */
     uint32_t g_shift;    /* queue order: 2^g_shift consecutive chunks of a pixel sit next to each other (see render_body) */
     uint32_t keep_num;   /* resumable tree traversal: go on while >= keep_num/64 of the traversing lanes are still at it (0: run to the end) */
@@ -1317,18 +1318,19 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 /* the queue runs through the band from its LAST pixel to its first: the sky gradient is the only light
                  * and cameras look roughly level, so the cheap one-segment paths (sky, top rows) end up in the tail
                  * of the launch and the long bounce chains at its start */
-                /* ... in passes of G = 2^g_shift chunks: (pass, pixel, chunk within the pass).  G trades two things: the 64
-                 * items a wave takes together should share pixels (rays of one pixel have the same candidates and the same
-                 * tree walk: G = all chunks is 4 % faster per segment than G = 1 on the bench frame), but 64 chunks of ONE
-                 * pixel on a glass ball are 64 paths to the depth limit that stall the wave and everything it has reserved
-                 * (short launches - an 8-GPU band - want a small G).  Slots beyond the last chunk (padding of the last
+                /* ... row by row, and within a row in passes of G = 2^g_shift chunks: (row, pass, x, chunk within the pass).
+                 * G trades two things: the 64 items a wave takes together should share pixels (rays of one pixel have the
+                 * same candidates and the same tree walk: G = all chunks is 4 % faster per segment than G = 1 on the bench
+                 * frame), but 64 chunks of ONE pixel on a glass ball are 64 paths to the depth limit that stall the wave and
+                 * everything it has reserved (short launches - an 8-GPU band - want a small G).  Rows stay outermost so that
+                 * ALL the work of the sky rows comes last, whatever G.  Slots beyond the last chunk (padding of the last
                  * pass) are skipped. */
                 const uint32_t rev = rp.n_items - 1u - got;
-                const uint32_t pass = fastdiv(rev, rp.d_pg), rem = rev - pass * (rp.n_pixels << rp.g_shift);
-                const uint32_t pl = rem >> rp.g_shift, ch = (pass << rp.g_shift) + (rem & ((1u << rp.g_shift) - 1u)); /* band pixel, row-major; chunk */
+                const uint32_t ly = fastdiv(rev, rp.d_row), rrow = rev - ly * rp.row_items;
+                const uint32_t pass = fastdiv(rrow, rp.d_pg), rem = rrow - pass * (cam.W << rp.g_shift);
+                lx = rem >> rp.g_shift;
+                const uint32_t ch = (pass << rp.g_shift) + (rem & ((1u << rp.g_shift) - 1u)); /* chunk */
                 item = rev; /* partial sums sit in queue order: the lanes of a wave store next to each other */
-                const uint32_t ly = fastdiv(pl, rp.d_W);
-                lx = pl - ly * cam.W;
                 gy = ly; /* part_global_row(part, ly) */
                 if (part.part_count > 1) {
                     const uint32_t ls = fastdiv(ly, rp.d_strip);
@@ -1526,10 +1528,10 @@ __global__ void resolve_kernel(const R* __restrict__ partial, DevCamera<R> cam, 
      * in chunk order, so the sum after the last pass is the one-call sum bit for bit */
     V3<R> acc = {(R)0.0, (R)0.0, (R)0.0};
     if (accum && rp.chunk_first != 0u) acc = {accum[o], accum[o + 1], accum[o + 2]};
-    /* queue order (render_body): [pass][pixel][chunk within the pass]; summed in chunk order whatever the pass size */
+    /* queue order (render_body): [row][pass][x][chunk within the pass]; summed in chunk order whatever the pass size */
     const uint32_t G = 1u << rp.g_shift;
-    const R* p = partial + ((size_t)pl << rp.g_shift) * 3;
-    for (uint32_t c0 = 0; c0 < rp.chunks; c0 += G, p += ((size_t)n_pixels << rp.g_shift) * 3) {
+    const R* p = partial + ((size_t)ly * rp.row_items + ((size_t)lx << rp.g_shift)) * 3;
+    for (uint32_t c0 = 0; c0 < rp.chunks; c0 += G, p += ((size_t)cam.W << rp.g_shift) * 3) {
         const uint32_t n = rp.chunks - c0 < G ? rp.chunks - c0 : G;
         for (uint32_t k = 0; k < n; ++k) acc = acc + V3<R>{p[3 * k], p[3 * k + 1], p[3 * k + 2]};
     }
