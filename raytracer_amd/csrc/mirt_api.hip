@@ -58,7 +58,7 @@ struct mirt_scene {
     mutable uint4* SM = nullptr;  /* operands and scale of the call being launched */
     mutable float mx_scale = 1.f;
     DevStats* stats = nullptr; /* one per scene: calls on one scene handle are not re-entrant */
-    std::vector<void*> allocs;
+    mutable std::vector<void*> allocs; /* everything freed with the scene (mutable: operand copies are made on first use) */
     /* render workspace (per-item partial sums), grown on demand and kept until the scene is destroyed */
     mutable void* partial = nullptr;
     mutable size_t partial_bytes = 0;
@@ -366,7 +366,7 @@ static int mx_ensure(const mirt_scene* s, const mirt_scene::MxSet& set, int e) {
         }
     uint4* dev = nullptr;
     HIP_TRY(hipMalloc((void**)&dev, SM.size() * sizeof(uint4)));
-    const_cast<mirt_scene*>(s)->allocs.push_back(dev);
+    s->allocs.push_back(dev);
     HIP_TRY(hipMemcpy(dev, SM.data(), SM.size() * sizeof(uint4), hipMemcpyHostToDevice));
     set.cache.emplace_back(e, dev);
     s->SM = dev;
