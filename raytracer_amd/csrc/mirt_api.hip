@@ -62,6 +62,7 @@ struct mirt_scene {
     /* render workspace (per-item partial sums), grown on demand and kept until the scene is destroyed */
     mutable void* partial = nullptr;
     mutable size_t partial_bytes = 0;
+    mutable hipEvent_t ev0 = nullptr, ev1 = nullptr; /* timing events of render calls that ask for statistics (created once) */
     int n_cus = 256;
 };
 
@@ -727,6 +728,8 @@ void mirt_scene_destroy(mirt_scene* s) {
     (void)hipSetDevice(s->device);
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->partial) (void)hipFree(s->partial);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
 }
 
@@ -773,13 +776,17 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (stats && !s->ev0) {
+        HIP_TRY(hipEventCreate(&s->ev0));
+        HIP_TRY(hipEventCreate(&s->ev1));
+    }
     int mx_e = 0;
     const bool mx = use_mx(s, cam, o, &mx_e);
     if (mx && (rc = mx_ensure(s, mx_set(s, o), mx_e))) return rc; /* before the timed region: the first call at a new scale uploads operands */
     HIP_TRY(hipMemsetAsync(s->stats, 0, sizeof(DevStats), st)); /* counters and the work-queue head */
     if (stats) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
+        e0 = s->ev0;
+        e1 = s->ev1;
         HIP_TRY(hipEventRecord(e0, st));
     }
     rc = o->precision == MIRT_F64
@@ -833,8 +840,6 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
             }
 #endif
         }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
     }
     return rc;
 }
