@@ -2,6 +2,8 @@
 for resident scenes inside the f16 range, split-f16 operands through v_mfma_f32_32x32x16_f16) - must select supersets of
 the exact candidates, i.e. give the same (id, t) for every ray: maps bit-exact against the f32 oracle and against each
 other, rendered images bit-identical, and the host must fall back to the vector ALU where the operands would not fit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -262,3 +264,15 @@ def test_f64_render_is_bit_identical_on_both_broad_phases(name):
     b, b8 = cam.render_arrays(sc, precision=abi.F64, seed=4, accel="valu")
     assert cam.last_stats["segments"] == seg
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64)) and np.array_equal(a8, b8)
+
+
+def test_fuzz_all_front_ends_against_the_oracle():
+    """A slice of tools/fuzz_maps.py (which was run over 360 scenes): random scenes, scales and cameras; every front end in
+    both precisions against the oracle."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_maps.py"), "4000", "8"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0 and "mismatching maps: 0" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
