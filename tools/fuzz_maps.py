@@ -1,4 +1,5 @@
-"""Fuzz: random scenes and cameras, hit-id / t maps of every closest-hit front end against the oracle (bit-exact).
+"""Fuzz: random scenes and cameras, hit-id / t maps of every closest-hit front end against the oracle (bit-exact), and
+small rendered frames of the front ends against each other (bit-identical).
 usage: PYTHONPATH=. python tools/fuzz_maps.py [first_seed] [n_cases]"""
 import os
 import sys
@@ -45,6 +46,15 @@ for case in range(n_cases):
             if not (np.array_equal(ids, o_ids) and np.array_equal(t.view(ut), o_t.view(ut))):
                 bad += 1
                 print(f"MISMATCH seed {seed0 + case} prec {prec} accel {accel}: {int((ids != o_ids).sum())} ids differ", flush=True)
+    # rendered frames (bounces, all materials, moving spheres at random times): bit-identical across the front ends
+    rcam = Camera.build(tuple((off + d * dist) * scale), tuple(off * scale), None, 48, 1.0, 2, 0.8, float(dist * scale), 0.01, 20)
+    for prec, ut in ((abi.F32, np.uint32), (abi.F64, np.uint64)):
+        ref, ref8 = rcam.render_arrays(sc, precision=prec, seed=case, accel="valu")
+        for accel in (None,) + (("bvh",) if prec == abi.F32 else ()):
+            lin, rgb8 = rcam.render_arrays(sc, precision=prec, seed=case, accel=accel)
+            if not (np.array_equal(lin.view(ut), ref.view(ut)) and np.array_equal(rgb8, ref8)):
+                bad += 1
+                print(f"RENDER MISMATCH seed {seed0 + case} prec {prec} accel {accel}", flush=True)
     print(f"case {seed0 + case}: n={n} scale=2^{int(np.log2(scale))} kinds {cam.closest_hit_kind(sc, precision=abi.F32)}/{cam.closest_hit_kind(sc, precision=abi.F64)} hits {int((o_ids != abi.MISS_ID).sum())}", flush=True)
 print("mismatching maps:", bad)
 sys.exit(1 if bad else 0)
