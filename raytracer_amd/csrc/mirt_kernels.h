@@ -917,6 +917,7 @@ struct TracerF64 {
     __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }
     __device__ inline const DevMaterial<double>& material_record(uint32_t idx) const { return sc.mats[material(idx)]; }
 };
+#define MIRT_TINY_SCENE 8u /* sorted slots (padded to groups of 4) */
 template <bool RES> struct TracerF32 {
     typedef float Real;
     static constexpr bool RESUMABLE = false;
@@ -924,6 +925,19 @@ template <bool RES> struct TracerF32 {
     F32Lds& L;
     uint32_t w;
     __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
+        if (RES && sc.n <= MIRT_TINY_SCENE) {
+            /* a handful of spheres (the textured presets have 1-3): the exact test on each of them, no lists, no broad
+             * phase - 16 bounding records per group would be mostly padding */
+            best.t = INFINITY;
+            best.idx = 0xFFFFFFFFu;
+            const float a = ray_a(ray.d);
+            if (active) {
+                for (uint32_t i = 0; i < sc.n; ++i) narrow_test(sc, GeomLds{L}, i, ray, a, tmin, best); /* dummy records never hit */
+                nc += sc.n;
+            }
+            pt.stamp(PH_NARROW);
+            return;
+        }
         trace_cons<RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
     }
     __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const {
