@@ -6,6 +6,10 @@ the ~485-sphere bouncing-balls scene, 1920x1080, 64 spp, depth 50) with the scen
 N GPUs (one process per GPU, torchrun): the frame is sharded in interleaved 8-row strips, every rank renders its
 band into HBM, the bands are gathered with RCCL (torch.distributed backend "nccl") and scattered into frame order
 by kernel K4.  Strong scaling: the frame is fixed, value = ray segments of the whole frame / time.
+On several GPUs up to 3 frames (--in-flight) are in flight at a time, each on its own stream and scene handle: the
+gather of one frame, and the few long paths that end it, run beside the next frame's kernel.  On one GPU the default
+is one frame at a time, so that every launch has the chip to itself and its HIP-event duration is the kernel's own
+(the roofline figure); the rate with 3 frames in flight is reported beside it (`frames_in_flight_3`).
 
 Prints ONE JSON line on rank 0 (see the task contract); extra keys: roofline, cpu_baseline, diagnostics.
 """
@@ -89,6 +93,10 @@ def main():
                     help="closest-hit method: brute = the brute-force tile loop (the metric; broad phase on the matrix pipe where the scene allows it), "
                          "valu = the same loop with the broad phase kept on the vector ALU, bvh = the bounding-ball tree")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra launches (valu_broad, accel_bvh): profiling runs want one kernel")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="frames in flight (ring of scene handles and streams); 1 = one frame at a time; 0 = 1 on one GPU "
+                         "(each launch alone on the chip: the kernel duration the roofline is priced with), 3 on several")
+    ap.add_argument("--force-dist", action="store_true", help="run the gather path with a process group of one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets N ranks rehearse the N>1 path on ONE GPU")
     args = ap.parse_args()
 
@@ -106,11 +114,19 @@ def main():
     local_rank %= torch.cuda.device_count()  # rehearsal on a one-GPU box: all ranks share device 0 (gloo only)
     torch.cuda.set_device(local_rank)
     td = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist  # --force-dist: the gather path with a process group of one (rehearsal on a one-GPU box)
+    if use_dist:
         import torch.distributed as td
 
+        if args.force_dist and "RANK" not in os.environ:
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": os.environ.get("MASTER_PORT", "29533"), "RANK": "0", "WORLD_SIZE": "1"})
         if args.backend == "nccl":
-            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            pg_opts = None
+            try:  # the gathers run beside the next frame's kernel: let their blocks have the first CUs that come free
+                pg_opts = td.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:
+                pass
+            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=pg_opts)
         else:
             td.init_process_group(args.backend)
 
@@ -120,39 +136,86 @@ def main():
     H, W, S = cam.height, cam.width, dist.DEFAULT_STRIP_ROWS
     real = torch.float32 if args.precision == 32 else torch.float64
     rows0 = dist.part_rows(H, S, 0, world)
-    band = torch.zeros((rows0, W, 3), dtype=real, device="cuda")
-    band8 = torch.zeros((rows0, W, 3), dtype=torch.uint8, device="cuda")
-    frame = torch.zeros((H, W, 3), dtype=real, device="cuda") if rank == 0 else None
+    accel_flags = {"brute": 0, "valu": abi.FLAG_VALU_BROAD, "bvh": abi.FLAG_BVH}[args.accel]
     opts = cam.opts(precision=args.precision, seed=args.seed, strip_rows=S, part_index=rank, part_count=world,
-                    flags=abi.FLAG_COMPACT_ROWS | {"brute": 0, "valu": abi.FLAG_VALU_BROAD, "bvh": abi.FLAG_BVH}[args.accel])
+                    flags=abi.FLAG_COMPACT_ROWS | abi.FLAG_DEFER_STATS | accel_flags)
     kind = lib.mirt_closest_hit_kind(ds.handle, C.byref(cam.pod), C.byref(opts))  # 0 valu, 1 matrix pipe, 2 tree, 3 f64, 4 f64 with the matrix-pipe broad phase
     abi.check(min(kind, 0))
     stream = torch.cuda.current_stream().cuda_stream
     elem = 3 * (4 if args.precision == 32 else 8)
 
-    def step():
-        st = abi.MirtStats()
-        abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(opts), band.data_ptr(), band8.data_ptr(), stream, C.byref(st)))
-        if world > 1:
-            allb = dist.gather_bands(band, world)  # RCCL all-gather over xGMI: the one exchange step
+    # Frames in flight.  A frame ends with a few long paths (glass, up to the depth limit) on a few CUs while the rest of
+    # the chip has nothing left to pull from the queue, and (N > 1) with the gather.  Each slot of the ring owns a scene
+    # handle (work queue + partial sums), a stream and its buffers, so the next frame's blocks take the CUs as they come
+    # free and the RCCL gather of frame f runs beside the kernel of frame f + 1.  Every frame is rendered, gathered and
+    # scattered in full; the statistics of a slot are collected (mirt_render_wait) before the slot is used again.
+    from raytracer_amd.api import DeviceScene
+
+    class Slot:
+        pass
+
+    depth = args.in_flight if args.in_flight > 0 else (3 if use_dist else 1)
+    ring = []
+    for i in range(depth):
+        sl = Slot()
+        sl.ds = ds if i == 0 else DeviceScene(scene.flat, local_rank)
+        sl.stream = torch.cuda.Stream() if depth > 1 else torch.cuda.current_stream()
+        sl.band = torch.zeros((rows0, W, 3), dtype=real, device="cuda")
+        sl.band8 = torch.zeros((rows0, W, 3), dtype=torch.uint8, device="cuda")
+        sl.allb = torch.zeros((world * rows0, W, 3), dtype=real, device="cuda") if use_dist else None
+        sl.frame = torch.zeros((H, W, 3), dtype=real, device="cuda") if rank == 0 else None
+        sl.busy = False
+        ring.append(sl)
+    band, band8 = ring[0].band, ring[0].band8
+    torch.cuda.synchronize()
+    stats = []
+
+    def collect(sl):
+        if sl.busy:
+            st = abi.MirtStats()
+            abi.check(lib.mirt_render_wait(sl.ds.handle, C.byref(st)))
+            sl.busy = False
+            stats.append(st)
+
+    def step(f):
+        sl = ring[f % depth]
+        collect(sl)
+        q = sl.stream.cuda_stream
+        abi.check(lib.mirt_render_device(sl.ds.handle, C.byref(cam.pod), C.byref(opts), sl.band.data_ptr(), sl.band8.data_ptr(), q, None))
+        sl.busy = True
+        if use_dist:
+            if args.backend != "nccl":
+                sl.stream.synchronize()  # rehearsal only: torch's gloo all-gather of a device tensor hangs on this image while its stream is busy (tools/gloo_probe.py)
+            with torch.cuda.stream(sl.stream):
+                td.all_gather_into_tensor(sl.allb, sl.band)  # RCCL all-gather over xGMI: the one exchange step
             if rank == 0:
-                abi.check(lib.mirt_deinterleave_device(allb.data_ptr(), band.numel() * band.element_size(), world, S, W, H, elem, frame.data_ptr(), stream))
+                abi.check(lib.mirt_deinterleave_device(sl.allb.data_ptr(), sl.band.numel() * sl.band.element_size(), world, S, W, H, elem, sl.frame.data_ptr(), q))
         else:
-            abi.check(lib.mirt_deinterleave_device(band.data_ptr(), band.numel() * band.element_size(), 1, S, W, H, elem, frame.data_ptr(), stream))
-        return st
+            abi.check(lib.mirt_deinterleave_device(sl.band.data_ptr(), sl.band.numel() * sl.band.element_size(), 1, S, W, H, elem, sl.frame.data_ptr(), q))
 
     def fence():
+        for sl in ring:
+            collect(sl)
         if td is not None:
             td.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for f in range(depth):  # set-up, untimed: every slot's first launch allocates its partial sums and uploads its operands
+        step(f)
     fence()
+    for f in range(args.warmup):
+        step(f)
+    fence()
+    stats.clear()
     t0 = time.perf_counter()
-    stats = [step() for _ in range(args.steps)]
+    for f in range(args.steps):
+        step(f)
     fence()
     elapsed = time.perf_counter() - t0
+    assert len(stats) == args.steps
+    if rank == 0 and depth > 1 and args.steps >= 2 and not torch.equal(ring[0].frame, ring[1].frame):
+        raise SystemExit("frames of two ring slots differ")
+    opts.flags &= ~abi.FLAG_DEFER_STATS
 
     seg = sum(s.segments for s in stats)
     flops = sum(18 * s.static_tests + 27 * s.moving_tests + 5 * s.segments for s in stats)
@@ -170,7 +233,9 @@ def main():
         seg_all, flops_all, iters_all, narrow_all = float(seg), float(flops), float(iters), float(narrow)
 
     if rank == 0:
-        achieved = (flops / (kern_ms * 1e-3)) / 1e12 if kern_ms > 0 else 0.0  # rank 0's kernel: per-GPU rate
+        # rank 0's kernel: per-GPU rate.  With frames in flight the launches share the chip (each one's event time spans
+        # its neighbours' too), so the rate is priced with this rank's share of the wall time instead: a lower bound.
+        achieved = (flops / ((kern_ms if depth == 1 else elapsed * 1e3) * 1e-3)) / 1e12 if kern_ms > 0 else 0.0
         out = {
             "metric": "Mrays/s at 1080p (ray segment = one closest-hit query) + % of FP32 VALU peak",
             "value": round(seg_all / elapsed / 1e6, 3),
@@ -187,6 +252,7 @@ def main():
             "config": {
                 "workload": f"{scene_name}: {scene.flat.n_spheres} spheres, {W}x{H}, {cam.pod.samples_per_pixel} spp, depth {cam.pod.max_bounce_depth}",
                 "parallelism": f"interleaved {S}-row strips over {world} GPU(s), RCCL all-gather of f32 RGB bands",
+                "frames_in_flight": depth,
                 "seed": args.seed,
                 "closest_hit": ["brute-force LDS tile loop, broad phase on the vector ALU",
                                 "brute-force LDS tile loop, broad-phase dot products on the matrix pipe (split-f16 MFMA), exact narrow phase on the vector ALU",
@@ -205,7 +271,8 @@ def main():
                 "kernel": ["render_kernel_f32", "render_kernel_f32_mx", "render_kernel_f32_bvh(_lds)", "render_kernel_f64<2>", "render_kernel_f64_mx"][kind],
                 "kernel_ms_avg": round(kern_ms / max(1, len(stats)), 3),
                 "flops_per_segment": round(flops / max(seg, 1), 1),
-                "note": "algorithmic flops = 18/static sphere test + 27/moving sphere test + 5/segment (SURVEY.md 8d); rank 0's launches"
+                "note": "algorithmic flops = 18/static sphere test + 27/moving sphere test + 5/segment (SURVEY.md 8d); rank 0's launches; duration = HIP events around each launch on its own stream"
+                        + ("" if depth == 1 else f"; {depth} frames in flight: launches overlap, `achieved` = this rank's flops / wall time of the timed region")
                         + ("; every (ray, sphere) pair is still tested, but the two dot products of the broad phase run on the matrix pipe, so the "
                            "algorithmic rate can exceed the vector-ALU peak it is priced against (DESIGN.md 5c; `valu_broad` below is the all-VALU kernel)" if kind == 1 else ""),
             },
@@ -216,6 +283,29 @@ def main():
                 "narrow_tests_per_segment": round(narrow_all / max(seg_all, 1.0), 3),
             },
         }
+        if world == 1 and depth == 1 and not use_dist and not args.no_extras:
+            # the same frames with 3 in flight (what the N > 1 runs do): the next frame's blocks take the CUs the last long paths leave idle
+            extra = [DeviceScene(scene.flat, local_rank) for _ in range(2)]
+            ring3 = [(ds, torch.cuda.Stream(), band, band8)] + [(e, torch.cuda.Stream(), torch.zeros_like(band), torch.zeros_like(band8)) for e in extra]
+            o5 = cam.opts(precision=args.precision, seed=args.seed, strip_rows=S, part_index=0, part_count=1, flags=abi.FLAG_COMPACT_ROWS | accel_flags)
+            n5 = max(6, args.steps)
+
+            def run3(n):
+                for f in range(n):
+                    h5, q5, b5, b85 = ring3[f % 3]
+                    abi.check(lib.mirt_render_device(h5.handle, C.byref(cam.pod), C.byref(o5), b5.data_ptr(), b85.data_ptr(), q5.cuda_stream, None))
+                torch.cuda.synchronize()
+
+            run3(3)
+            t5 = time.perf_counter()
+            run3(n5)
+            dt5 = (time.perf_counter() - t5) / n5
+            if not (torch.equal(ring3[0][2], ring3[1][2]) and torch.equal(ring3[0][2], ring3[2][2])):
+                raise SystemExit("frames of the three ring slots differ")
+            out["frames_in_flight_3"] = {"value": round(seg / args.steps / dt5 / 1e6, 3), "unit": "Mrays/s", "ms_per_frame": round(dt5 * 1e3, 3), "frames": n5,
+                                         "note": "same frame, three scene handles on three streams; the N > 1 runs keep frames in flight like this"}
+            for e in extra:
+                e.close()
         if world == 1 and kind == 1 and not args.no_extras:
             # the same frame with the broad phase on the vector ALU (MIRT_FLAG_VALU_BROAD): the kernel the VALU roofline describes directly
             o3 = cam.opts(precision=32, seed=args.seed, strip_rows=S, part_index=0, part_count=1, flags=abi.FLAG_COMPACT_ROWS | abi.FLAG_VALU_BROAD)

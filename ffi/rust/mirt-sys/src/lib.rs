@@ -27,6 +27,7 @@ pub const MIRT_F32: u32 = 32;
 pub const MIRT_FLAG_COMPACT_ROWS: u32 = 1;
 pub const MIRT_FLAG_BVH: u32 = 2;
 pub const MIRT_FLAG_VALU_BROAD: u32 = 4;
+pub const MIRT_FLAG_DEFER_STATS: u32 = 8;
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -154,6 +155,7 @@ extern "C" {
     pub fn mirt_part_rows(height: u32, strip_rows: u32, part_index: u32, part_count: u32) -> u32;
     pub fn mirt_render_pass_device(scene: *const mirt_scene, cam: *const mirt_camera, opts: *const mirt_opts, first_sample: u32, sample_count: u32, d_accum: *mut c_void, d_rgb_linear: *mut c_void, d_rgb8: *mut u8, stream: *mut c_void, stats: *mut mirt_stats) -> c_int;
     pub fn mirt_render_pass(scene: *const mirt_scene, cam: *const mirt_camera, opts: *const mirt_opts, first_sample: u32, sample_count: u32, accum: *mut c_void, rgb_linear: *mut c_void, rgb8: *mut u8, stats: *mut mirt_stats) -> c_int;
+    pub fn mirt_render_wait(scene: *const mirt_scene, stats: *mut mirt_stats) -> c_int;
     pub fn mirt_pass_granularity(cam: *const mirt_camera, opts: *const mirt_opts) -> u32;
     pub fn mirt_closest_hit_kind(scene: *const mirt_scene, cam: *const mirt_camera, opts: *const mirt_opts) -> c_int;
     pub fn mirt_philox4x32_10(ctr: *const u32, key: *const u32, out: *mut u32);

@@ -127,6 +127,11 @@ typedef enum mirt_precision {
  * split-f16 operands run the broad phase's dot products on the matrix pipe (v_mfma_f32_32x32x16_f16); the candidates go
  * through the same exact test either way, so the (id, t) of every ray - and the image - do not depend on this flag. */
 #define MIRT_FLAG_VALU_BROAD 4u
+/* Device-buffer render calls: do not wait for the launch.  The call records its timing events and sends the counters to
+ * pinned host memory behind the kernels, returns at once (its `stats` argument is ignored) and mirt_render_wait() on
+ * the same scene handle collects them later.  For callers that keep several frames in flight - one scene handle and
+ * one stream per frame in flight, since a handle owns one work queue and one set of partial sums. */
+#define MIRT_FLAG_DEFER_STATS 8u
 
 /* Which rows a call renders: rows are grouped in strips of `strip_rows`; strip s is owned when
  * s % part_count == part_index (interleaved strips).  part_count <= 1 = whole image. */
@@ -187,6 +192,10 @@ int mirt_render_device(const mirt_scene* scene, const mirt_camera* cam, const mi
                        void* d_rgb_linear, uint8_t* d_rgb8, void* stream, mirt_stats* stats);
 int mirt_primary_hits_device(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
                              uint32_t* d_id, void* d_t, void* stream);
+/* Waits for the render call made with MIRT_FLAG_DEFER_STATS on this scene handle (no reference counterpart: the
+ * reference's render returns when the frame is done) and fills `stats` (may be NULL).  Until it has been called, further
+ * render calls on the handle are refused; without the flag there is nothing to wait for and the call is an error. */
+int mirt_render_wait(const mirt_scene* scene, mirt_stats* stats);
 
 /* K3 alone: gamma-2 + quantise n reals (device pointers) exactly like rgb.rs:20-36 and
  * utils/math.rs:13-21.  *nan_count receives how many inputs were NaN (host pointer, may be NULL). */

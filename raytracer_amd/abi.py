@@ -11,6 +11,7 @@ MISS_ID = 0xFFFFFFFF
 F64, F32 = 64, 32
 FLAG_COMPACT_ROWS = 1
 FLAG_BVH = 2  # closest hit through the bounding-ball tree (f32 only); same image bit for bit
+FLAG_DEFER_STATS = 8  # _device render calls: return at once, mirt_render_wait() collects the statistics
 FLAG_VALU_BROAD = 4  # f32 brute force: broad phase on the vector ALU instead of the matrix pipe; same image bit for bit
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
@@ -120,6 +121,7 @@ EXPORTS = [
     "mirt_render_pass_device",
     "mirt_render_pass",
     "mirt_pass_granularity",
+    "mirt_render_wait",
     "mirt_philox4x32_10",
 ]
 
@@ -173,6 +175,8 @@ def load():
     lib.mirt_render_pass.argtypes = [vp, P(MirtCamera), P(MirtOpts), u32, u32, vp, vp, vp, P(MirtStats)]
     lib.mirt_pass_granularity.argtypes = [P(MirtCamera), P(MirtOpts)]
     lib.mirt_pass_granularity.restype = u32
+    lib.mirt_render_wait.argtypes = [vp, P(MirtStats)]
+    lib.mirt_render_wait.restype = C.c_int
     lib.mirt_closest_hit_kind.argtypes = [vp, P(MirtCamera), P(MirtOpts)]
     lib.mirt_closest_hit_kind.restype = C.c_int
     lib.mirt_philox4x32_10.argtypes = [P(u32), P(u32), P(u32)]

@@ -63,6 +63,11 @@ struct mirt_scene {
     mutable void* partial = nullptr;
     mutable size_t partial_bytes = 0;
     mutable hipEvent_t ev0 = nullptr, ev1 = nullptr; /* timing events of render calls that ask for statistics (created once) */
+    /* MIRT_FLAG_DEFER_STATS: the counters land in pinned host memory behind the launch, mirt_render_wait reads them */
+    mutable hipEvent_t ev2 = nullptr;
+    mutable DevStats* host_stats = nullptr;
+    mutable bool pending = false;
+    mutable uint32_t pending_flags = 0;
     int n_cus = 256;
 };
 
@@ -730,6 +735,8 @@ void mirt_scene_destroy(mirt_scene* s) {
     if (s->partial) (void)hipFree(s->partial);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->ev2) (void)hipEventDestroy(s->ev2);
+    if (s->host_stats) (void)hipHostFree(s->host_stats);
     delete s;
 }
 
@@ -767,6 +774,30 @@ uint32_t mirt_pass_granularity(const mirt_camera* cam, const mirt_opts* o) {
     choose_chunks((uint64_t)cam->img_width * part.local_rows, cam->samples_per_pixel, o->precision == MIRT_F64 ? 8 : 4, &chunk, &chunks);
     return chunk;
 }
+static void fill_stats(const mirt_scene* s, uint32_t flags, const DevStats& h, float ms, mirt_stats* stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->segments = h.segments;
+    stats->tree_segments = (flags & MIRT_FLAG_BVH) ? h.segments : 0;
+    const uint64_t brute = h.segments - stats->tree_segments;
+    stats->static_tests = brute * (uint64_t)s->true_static;
+    stats->moving_tests = brute * (uint64_t)(s->true_n - s->true_static);
+    stats->sphere_tests = stats->static_tests + stats->moving_tests;
+    stats->narrow_tests = h.narrow;
+    stats->wave_iterations = h.wave_iters;
+    stats->nan_pixels = h.nan_pixels;
+    stats->kernel_ms = ms;
+}
+int mirt_render_wait(const mirt_scene* s, mirt_stats* stats) {
+    if (!s) return fail(MIRT_ERR_INVALID, "null argument");
+    if (!s->pending) return fail(MIRT_ERR_INVALID, "no deferred render outstanding on this scene handle");
+    s->pending = false;
+    hipError_t e = hipEventSynchronize(s->ev2);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, s->ev0, s->ev1);
+    if (e != hipSuccess) return fail(MIRT_ERR_HIP, std::string("render: ") + hipGetErrorString(e));
+    if (stats) fill_stats(s, s->pending_flags, *s->host_stats, ms, stats);
+    return MIRT_OK;
+}
 static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t first_sample, uint32_t sample_count, void* d_accum,
                        void* d_lin, uint8_t* d_rgb8, void* stream, mirt_stats* stats) {
     int rc = check_common(s, cam, o);
@@ -776,15 +807,22 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (stats && !s->ev0) {
+    const bool defer = (o->flags & MIRT_FLAG_DEFER_STATS) != 0;
+    if (defer) stats = nullptr; /* they come from mirt_render_wait */
+    if ((stats || defer) && !s->ev0) {
         HIP_TRY(hipEventCreate(&s->ev0));
         HIP_TRY(hipEventCreate(&s->ev1));
     }
+    if (defer && !s->ev2) {
+        HIP_TRY(hipEventCreate(&s->ev2));
+        HIP_TRY(hipHostMalloc((void**)&s->host_stats, sizeof(DevStats), hipHostMallocDefault));
+    }
+    if (s->pending) return fail(MIRT_ERR_INVALID, "a deferred render on this scene handle has not been collected (mirt_render_wait)");
     int mx_e = 0;
     const bool mx = use_mx(s, cam, o, &mx_e);
     if (mx && (rc = mx_ensure(s, mx_set(s, o), mx_e))) return rc; /* before the timed region: the first call at a new scale uploads operands */
     HIP_TRY(hipMemsetAsync(s->stats, 0, sizeof(DevStats), st)); /* counters and the work-queue head */
-    if (stats) {
+    if (stats || defer) {
         e0 = s->ev0;
         e1 = s->ev1;
         HIP_TRY(hipEventRecord(e0, st));
@@ -792,6 +830,13 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
     rc = o->precision == MIRT_F64
              ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st, false, mx, first_sample, sample_count, d_accum)
              : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0, mx, first_sample, sample_count, d_accum);
+    if (defer && !rc) { /* nothing waits here: the counters follow the launch into pinned memory */
+        HIP_TRY(hipEventRecord(e1, st));
+        HIP_TRY(hipMemcpyAsync(s->host_stats, s->stats, sizeof(DevStats), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(s->ev2, st));
+        s->pending = true;
+        s->pending_flags = o->flags;
+    }
     if (stats) {
         if (!rc) {
             hipError_t e = hipEventRecord(e1, st);
@@ -802,17 +847,7 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
             if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
             if (e == hipSuccess) e = hipMemcpy(&h, s->stats, sizeof(h), hipMemcpyDeviceToHost);
             if (e != hipSuccess) rc = fail(MIRT_ERR_HIP, std::string("render: ") + hipGetErrorString(e));
-            memset(stats, 0, sizeof(*stats));
-            stats->segments = h.segments;
-            stats->tree_segments = (o->flags & MIRT_FLAG_BVH) ? h.segments : 0;
-            const uint64_t brute = h.segments - stats->tree_segments;
-            stats->static_tests = brute * (uint64_t)s->true_static;
-            stats->moving_tests = brute * (uint64_t)(s->true_n - s->true_static);
-            stats->sphere_tests = stats->static_tests + stats->moving_tests;
-            stats->narrow_tests = h.narrow;
-            stats->wave_iterations = h.wave_iters;
-            stats->nan_pixels = h.nan_pixels;
-            stats->kernel_ms = ms;
+            fill_stats(s, o->flags, h, ms, stats);
 #ifdef MIRT_VERIFY_BROAD
             fprintf(stderr, "[mirt verify broad] exact candidates missed by the conservative broad phase: %llu\n", h.broad_misses);
 #endif
@@ -849,6 +884,7 @@ int mirt_primary_hits(const mirt_scene* s, const mirt_camera* cam, const mirt_op
     if (rc) return rc;
     if (!id) return fail(MIRT_ERR_INVALID, "id output is required");
     if (o->flags & MIRT_FLAG_COMPACT_ROWS) return fail(MIRT_ERR_INVALID, "host-buffer calls write full frames; use the _device entry point for compact bands");
+    if (o->flags & MIRT_FLAG_DEFER_STATS) return fail(MIRT_ERR_INVALID, "host-buffer calls return when the work is done; MIRT_FLAG_DEFER_STATS is for mirt_render_device / mirt_render_pass_device");
     HIP_TRY(hipSetDevice(s->device));
     size_t npx = (size_t)cam->img_width * cam->img_height;
     size_t rsz = o->precision == MIRT_F64 ? 8 : 4;
@@ -873,6 +909,7 @@ int mirt_render(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o,
     int rc = check_common(s, cam, o);
     if (rc) return rc;
     if (o->flags & MIRT_FLAG_COMPACT_ROWS) return fail(MIRT_ERR_INVALID, "host-buffer calls write full frames; use the _device entry point for compact bands");
+    if (o->flags & MIRT_FLAG_DEFER_STATS) return fail(MIRT_ERR_INVALID, "host-buffer calls return when the work is done; MIRT_FLAG_DEFER_STATS is for mirt_render_device / mirt_render_pass_device");
     HIP_TRY(hipSetDevice(s->device));
     size_t n = (size_t)cam->img_width * cam->img_height * 3;
     size_t rsz = o->precision == MIRT_F64 ? 8 : 4;
@@ -899,6 +936,7 @@ int mirt_render_pass(const mirt_scene* s, const mirt_camera* cam, const mirt_opt
     int rc = check_common(s, cam, o);
     if (rc) return rc;
     if (o->flags & MIRT_FLAG_COMPACT_ROWS) return fail(MIRT_ERR_INVALID, "host-buffer calls write full frames; use the _device entry point for compact bands");
+    if (o->flags & MIRT_FLAG_DEFER_STATS) return fail(MIRT_ERR_INVALID, "host-buffer calls return when the work is done; MIRT_FLAG_DEFER_STATS is for mirt_render_device / mirt_render_pass_device");
     if (!accum) return fail(MIRT_ERR_INVALID, "pass: the accumulation buffer is required");
     HIP_TRY(hipSetDevice(s->device));
     const size_t n = (size_t)cam->img_width * cam->img_height * 3, rsz = o->precision == MIRT_F64 ? 8 : 4;

@@ -444,3 +444,45 @@ def test_progressive_passes_on_compact_bands(scenes):
     torch.cuda.synchronize()
     frame = dist.deinterleave_host(bands.cpu().numpy(), H, S)
     assert np.array_equal(frame.view(np.uint8), ref.view(np.uint8))
+
+
+def test_deferred_statistics_and_frames_in_flight(scenes):
+    """MIRT_FLAG_DEFER_STATS: the call returns behind its launch, mirt_render_wait collects the same statistics later.  Three
+    frames in flight on three scene handles and streams (what bench.py does on several GPUs) are the frames of three
+    calls made one after the other, and a handle refuses a second launch before the first has been collected."""
+    import torch
+
+    from raytracer_amd.api import DeviceScene
+
+    sc, cam = scenes["balls"], SCENES["balls"][1](160, 8, 30)
+    cam.precision = abi.F32
+    ref, ref8 = cam.render_arrays(sc, seed=4)
+    seg_ref = cam.last_stats["segments"]
+    lib = abi.load()
+    H, W = cam.height, cam.width
+    handles = [DeviceScene(sc.flat, 0) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    lin = [torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(3)]
+    rgb = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    o = cam.opts(precision=abi.F32, seed=4, flags=abi.FLAG_DEFER_STATS)
+    st = abi.MirtStats()
+    with pytest.raises(abi.MirtError):  # nothing outstanding yet
+        abi.check(lib.mirt_render_wait(handles[0].handle, C.byref(st)))
+    for rounds in range(2):
+        for i in range(3):
+            abi.check(lib.mirt_render_device(handles[i].handle, C.byref(cam.pod), C.byref(o), lin[i].data_ptr(), rgb[i].data_ptr(), streams[i].cuda_stream, None))
+        with pytest.raises(abi.MirtError):  # handle 1 still owes its statistics
+            abi.check(lib.mirt_render_device(handles[1].handle, C.byref(cam.pod), C.byref(o), lin[1].data_ptr(), rgb[1].data_ptr(), streams[1].cuda_stream, None))
+        for i in (2, 0, 1):  # any order
+            abi.check(lib.mirt_render_wait(handles[i].handle, C.byref(st)))
+            assert st.segments == seg_ref and st.kernel_ms > 0.0
+        with pytest.raises(abi.MirtError):
+            abi.check(lib.mirt_render_wait(handles[0].handle, None))
+        torch.cuda.synchronize()
+        for i in range(3):
+            assert np.array_equal(lin[i].cpu().numpy().view(np.uint8), ref.view(np.uint8)) and np.array_equal(rgb[i].cpu().numpy(), ref8)
+            lin[i].zero_()
+    with pytest.raises(abi.MirtError):  # host-buffer calls return when the frame is done: the flag is refused
+        abi.check(lib.mirt_render(handles[0].handle, C.byref(cam.pod), C.byref(o), None, None, None))
+    for h in handles:
+        h.close()
