@@ -673,7 +673,9 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
  * lane, lane + 64, ... and the wave reduces (t, hit id) to the minimum - the same closest hit, since the exact test is
  * all the broad phases ever filter for.  ~8 rounds of one exact test per ray for the bench scene instead of 16 tiles of
  * matrix work: the tail of an 8-GPU band shrinks from ~1 ms to ~0.2 ms. */
+#ifndef MIRT_FEW_LANES
 #define MIRT_FEW_LANES 4u
+#endif
 template <class R, class G>
 __device__ inline void trace_few(const DevScene<R>& sc, const G& geo, uint32_t lane, unsigned long long live, const RayT<R>& ray, R tmin, Closest<R>& best,
                                  uint32_t& narrow_count) {
