@@ -266,7 +266,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
                 # HBM bytes per launch of this kernel, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE in separate passes
-                # (profiles/r01_v5_hbm_traffic.txt; not re-measured by this script).  Only quoted for the workload it was taken on.
+                # (profiles/r01_mx_hbm_traffic.txt: 17-35 MiB fetched + 772 MiB written, the per-item partial sums; not re-measured by this script).  Only quoted for the workload it was taken on.
                 "traffic": 8.3e8 if (args.workload == "balls1080p" and (W, cam.pod.samples_per_pixel, world) == (1920, 64, 1) and kind in (0, 1)) else None,
                 "kernel": ["render_kernel_f32", "render_kernel_f32_mx", "render_kernel_f32_bvh(_lds)", "render_kernel_f64<2>", "render_kernel_f64_mx"][kind],
                 "kernel_ms_avg": round(kern_ms / max(1, len(stats)), 3),
