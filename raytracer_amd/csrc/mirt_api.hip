@@ -774,6 +774,36 @@ uint32_t mirt_pass_granularity(const mirt_camera* cam, const mirt_opts* o) {
     choose_chunks((uint64_t)cam->img_width * part.local_rows, cam->samples_per_pixel, o->precision == MIRT_F64 ? 8 : 4, &chunk, &chunks);
     return chunk;
 }
+/* diagnostic builds (-DMIRT_VERIFY_BROAD, -DMIRT_PHASE_TIMING, ...): what the kernels counted, on stderr */
+static void print_diagnostics(const DevStats& h) {
+    (void)h;
+#ifdef MIRT_VERIFY_BROAD
+    fprintf(stderr, "[mirt verify broad] exact candidates missed by the conservative broad phase: %llu\n", h.broad_misses);
+#endif
+#ifdef MIRT_PHASE_TIMING
+    {
+        static const char* names[6] = {"queue", "raygen", "broad", "narrow", "shade", "other"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 6; ++i) tot += h.phase_cycles[i];
+        fprintf(stderr, "[mirt phase timing] wave-cycles:");
+        for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h.phase_cycles[i] / (double)(tot ? tot : 1));
+        fprintf(stderr, "  (total %.3g cycles, %.0f per wave-iteration)\n", (double)tot, (double)tot / (double)(h.wave_iters ? h.wave_iters : 1));
+#ifdef MIRT_ACTIVE_HIST
+        fprintf(stderr, "[mirt active-lane histogram] wave-iterations with 1-2 / 3-8 / 9-32 / 33-64 active lanes: %llu %llu %llu %llu of %llu\n", h.bvh_lane_steps,
+                h.bvh_wave_steps, h.bvh_leaf_rounds, h.bvh_lane_leaves, h.wave_iters);
+#else
+        if (h.bvh_wave_steps)
+            fprintf(stderr, "[mirt phase timing] tree: %.1f node steps per segment, %.1f wave-level steps and %.2f leaf rounds per wave-iteration, %.2f leaves per segment\n",
+                    (double)h.bvh_lane_steps / (double)(h.segments ? h.segments : 1), (double)h.bvh_wave_steps / (double)(h.wave_iters ? h.wave_iters : 1),
+                    (double)h.bvh_leaf_rounds / (double)(h.wave_iters ? h.wave_iters : 1), (double)h.bvh_lane_leaves / (double)(h.segments ? h.segments : 1));
+#endif
+        double span = (double)(h.end_max - ~h.inv_start_max) * 1e-5; /* 100 MHz ticks -> ms */
+        double life = (double)h.life_sum / (double)(h.n_waves ? h.n_waves : 1) * 1e-5;
+        fprintf(stderr, "[mirt phase timing] %llu waves, first start -> last end %.3f ms, mean wave lifetime %.3f ms (%.1f%% of the span)\n",
+                h.n_waves, span, life, 100.0 * life / (span > 0 ? span : 1));
+    }
+#endif
+}
 static void fill_stats(const mirt_scene* s, uint32_t flags, const DevStats& h, float ms, mirt_stats* stats) {
     memset(stats, 0, sizeof(*stats));
     stats->segments = h.segments;
@@ -796,6 +826,7 @@ int mirt_render_wait(const mirt_scene* s, mirt_stats* stats) {
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, s->ev0, s->ev1);
     if (e != hipSuccess) return fail(MIRT_ERR_HIP, std::string("render: ") + hipGetErrorString(e));
     if (stats) fill_stats(s, s->pending_flags, *s->host_stats, ms, stats);
+    print_diagnostics(*s->host_stats);
     return MIRT_OK;
 }
 static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t first_sample, uint32_t sample_count, void* d_accum,
@@ -848,32 +879,7 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
             if (e == hipSuccess) e = hipMemcpy(&h, s->stats, sizeof(h), hipMemcpyDeviceToHost);
             if (e != hipSuccess) rc = fail(MIRT_ERR_HIP, std::string("render: ") + hipGetErrorString(e));
             fill_stats(s, o->flags, h, ms, stats);
-#ifdef MIRT_VERIFY_BROAD
-            fprintf(stderr, "[mirt verify broad] exact candidates missed by the conservative broad phase: %llu\n", h.broad_misses);
-#endif
-#ifdef MIRT_PHASE_TIMING
-            {
-                static const char* names[6] = {"queue", "raygen", "broad", "narrow", "shade", "other"};
-                unsigned long long tot = 0;
-                for (int i = 0; i < 6; ++i) tot += h.phase_cycles[i];
-                fprintf(stderr, "[mirt phase timing] wave-cycles:");
-                for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h.phase_cycles[i] / (double)(tot ? tot : 1));
-                fprintf(stderr, "  (total %.3g cycles, %.0f per wave-iteration)\n", (double)tot, (double)tot / (double)(h.wave_iters ? h.wave_iters : 1));
-#ifdef MIRT_ACTIVE_HIST
-                fprintf(stderr, "[mirt active-lane histogram] wave-iterations with 1-2 / 3-8 / 9-32 / 33-64 active lanes: %llu %llu %llu %llu of %llu\n", h.bvh_lane_steps,
-                        h.bvh_wave_steps, h.bvh_leaf_rounds, h.bvh_lane_leaves, h.wave_iters);
-#else
-                if (h.bvh_wave_steps)
-                    fprintf(stderr, "[mirt phase timing] tree: %.1f node steps per segment, %.1f wave-level steps and %.2f leaf rounds per wave-iteration, %.2f leaves per segment\n",
-                            (double)h.bvh_lane_steps / (double)(h.segments ? h.segments : 1), (double)h.bvh_wave_steps / (double)(h.wave_iters ? h.wave_iters : 1),
-                            (double)h.bvh_leaf_rounds / (double)(h.wave_iters ? h.wave_iters : 1), (double)h.bvh_lane_leaves / (double)(h.segments ? h.segments : 1));
-#endif
-                double span = (double)(h.end_max - ~h.inv_start_max) * 1e-5; /* 100 MHz ticks -> ms */
-                double life = (double)h.life_sum / (double)(h.n_waves ? h.n_waves : 1) * 1e-5;
-                fprintf(stderr, "[mirt phase timing] %llu waves, first start -> last end %.3f ms, mean wave lifetime %.3f ms (%.1f%% of the span)\n",
-                        h.n_waves, span, life, 100.0 * life / (span > 0 ? span : 1));
-            }
-#endif
+            print_diagnostics(h);
         }
     }
     return rc;
