@@ -486,3 +486,15 @@ def test_deferred_statistics_and_frames_in_flight(scenes):
         abi.check(lib.mirt_render(handles[0].handle, C.byref(cam.pod), C.byref(o), None, None, None))
     for h in handles:
         h.close()
+
+
+def test_fuzz_radiance_against_the_oracle():
+    """A slice of tools/fuzz_radiance.py (run over 1200 scenes, profiles/r01_microbench.txt): random scenes with every material
+    and texture kind, random cameras, both precisions, every front end, same seeded RNG on both sides."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_radiance.py"), "7000", "12"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0 and "failing renders: 0" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
