@@ -187,7 +187,7 @@ def main():
             if args.backend != "nccl":
                 sl.stream.synchronize()  # rehearsal only: torch's gloo all-gather of a device tensor hangs on this image while its stream is busy (tools/gloo_probe.py)
             with torch.cuda.stream(sl.stream):
-                td.all_gather_into_tensor(sl.allb, sl.band)  # RCCL all-gather over xGMI: the one exchange step
+                dist.gather_bands_into(sl.allb, sl.band)  # RCCL all-gather over xGMI: the one exchange step
             if rank == 0:
                 abi.check(lib.mirt_deinterleave_device(sl.allb.data_ptr(), sl.band.numel() * sl.band.element_size(), world, S, W, H, elem, sl.frame.data_ptr(), q))
         else:

@@ -45,3 +45,13 @@ def gather_bands(band, world_size: int):
     out = torch.empty((world_size * band.shape[0],) + tuple(band.shape[1:]), dtype=band.dtype, device=band.device)
     td.all_gather_into_tensor(out, band.contiguous())
     return out.view((world_size,) + tuple(band.shape))
+
+
+def gather_bands_into(out, band) -> None:
+    """The same exchange into a caller-owned (world_size * rows, ...) tensor, on torch's current stream: what bench.py
+    calls once per frame and ring slot, so that nothing is allocated while frames are in flight."""
+    import torch.distributed as td
+
+    if out.shape[0] % band.shape[0] != 0 or tuple(out.shape[1:]) != tuple(band.shape[1:]) or out.dtype != band.dtype:
+        raise ValueError(f"gather buffer {tuple(out.shape)} {out.dtype} does not hold whole bands of {tuple(band.shape)} {band.dtype}")
+    td.all_gather_into_tensor(out, band)

@@ -41,6 +41,15 @@ def _worker(rank, world, port, height, width, strip, q):
         band[: len(rows)] = full[rows]
         bands = dist.gather_bands(torch.from_numpy(band), world)
         frame = dist.deinterleave_host(bands.numpy(), height, strip)
+        # bench.py's form: a ring of caller-owned gather buffers, one frame per slot (frames differ by a constant here)
+        ring = [torch.zeros((world * max_rows, width, 3), dtype=torch.float32) for _ in range(3)]
+        for f in range(5):
+            dist.gather_bands_into(ring[f % 3], torch.from_numpy(band + np.float32(f)))
+        for f in (2, 3, 4):
+            got = dist.deinterleave_host(ring[f % 3].numpy().reshape(world, max_rows, width, 3), height, strip)
+            assert np.array_equal(got, full + np.float32(f))
+        with pytest.raises(ValueError):
+            dist.gather_bands_into(torch.zeros((world * max_rows + 1, width, 3)), torch.from_numpy(band))
         # the timing reduction bench.py does: max over ranks
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
