@@ -572,8 +572,10 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
         launch_render_kernel((uint32_t)grid, block, bvh, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, rp, (R*)s->partial, s->stats);
         HIP_TRY(hipGetLastError());
     }
-    uint32_t rgrid = (uint32_t)((n_pixels + 255) / 256);
-    hipLaunchKernelGGL((resolve_kernel<R>), dim3(rgrid), dim3(256), 0, st, (const R*)s->partial, dev_camera<R>(cam), part, rp, (uint32_t)n_pixels,
+    /* one wave per 64 pixels of a band row */
+    const uint64_t rwaves = (uint64_t)part.local_rows * ((cam->img_width + 63u) / 64u);
+    uint32_t rgrid = (uint32_t)((rwaves + MIRT_RESOLVE_WAVES - 1) / MIRT_RESOLVE_WAVES);
+    hipLaunchKernelGGL((resolve_kernel<R>), dim3(rgrid), dim3(MIRT_RESOLVE_WAVES * MIRT_WAVE), 0, st, (const R*)s->partial, dev_camera<R>(cam), part, rp, (uint32_t)n_pixels,
                        (R*)d_lin, d_rgb8, s->stats, (R*)d_accum);
     HIP_TRY(hipGetLastError());
     return MIRT_OK;

@@ -1533,26 +1533,53 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
 }
 
 /* ---- K2b (+K3): add the chunks of a pixel in chunk order, scale by 1/spp (camera.rs:246), gamma + quantise
- *      (rgb.rs:20-36).  One thread per band pixel. */
+ *      (rgb.rs:20-36).  One wave per 64 consecutive pixels of a band row, one lane per pixel.  The partial sums sit in
+ *      queue order - per row and pass, pixel by pixel, a pixel's chunks next to each other - so a lane that walked its
+ *      own pixel's chunks would touch a different cache line than its neighbours with every load.  Instead the wave
+ *      copies MIRT_RESOLVE_TC chunks of its 64 pixels at a time into LDS with consecutive lanes on consecutive words,
+ *      and each lane adds its pixel's chunks from there, in chunk order as before (bit-identical sums). */
+#define MIRT_RESOLVE_TC 8u
+#define MIRT_RESOLVE_WAVES 4u
 template <class R>
-__global__ void resolve_kernel(const R* __restrict__ partial, DevCamera<R> cam, DevPart part, RenderParams rp, uint32_t n_pixels,
-                               R* __restrict__ out_lin, uint8_t* __restrict__ out_rgb8, DevStats* __restrict__ stats, R* accum) {
-    uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pl >= n_pixels) return;
-    const uint32_t ly = pl / cam.W, lx = pl - ly * cam.W;
-    const uint32_t row = part.compact ? ly : part_global_row(part, ly);
+__global__ __launch_bounds__(MIRT_RESOLVE_WAVES * MIRT_WAVE) void resolve_kernel(const R* __restrict__ partial, DevCamera<R> cam, DevPart part, RenderParams rp,
+                                                                                   uint32_t n_pixels, R* __restrict__ out_lin, uint8_t* __restrict__ out_rgb8,
+                                                                                   DevStats* __restrict__ stats, R* accum) {
+    constexpr uint32_t TC = MIRT_RESOLVE_TC, STRIDE = TC * 3u + 1u; /* odd stride: the lanes' rows start in different banks */
+    __shared__ R tile_all[MIRT_RESOLVE_WAVES][MIRT_WAVE * STRIDE];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    R* tile = tile_all[w];
+    const uint32_t segs = (cam.W + 63u) / 64u;
+    const uint32_t wave_id = blockIdx.x * MIRT_RESOLVE_WAVES + w;
+    const uint32_t ly = wave_id / segs, lx0 = (wave_id - ly * segs) * 64u;
+    /* waves beyond the band take part in the barriers with no pixels (the trip counts below are the same for every wave) */
+    const uint32_t nvalid = ly < part.local_rows ? (cam.W - lx0 < 64u ? cam.W - lx0 : 64u) : 0u;
+    const bool valid = lane < nvalid;
+    const uint32_t lx = lx0 + lane;
+    const uint32_t row = (part.compact || !valid) ? ly : part_global_row(part, ly);
     const size_t o = ((size_t)row * cam.W + lx) * 3;
     /* progressive passes carry the running sum of the earlier chunks in `accum` (same layout as the output) and go on adding
      * in chunk order, so the sum after the last pass is the one-call sum bit for bit */
     V3<R> acc = {(R)0.0, (R)0.0, (R)0.0};
-    if (accum && rp.chunk_first != 0u) acc = {accum[o], accum[o + 1], accum[o + 2]};
+    if (valid && accum && rp.chunk_first != 0u) acc = {accum[o], accum[o + 1], accum[o + 2]};
     /* queue order (render_body): [row][pass][x][chunk within the pass]; summed in chunk order whatever the pass size */
     const uint32_t G = 1u << rp.g_shift;
-    const R* p = partial + ((size_t)ly * rp.row_items + ((size_t)lx << rp.g_shift)) * 3;
+    const R* p = partial + ((size_t)(nvalid ? ly : 0u) * rp.row_items + ((size_t)(nvalid ? lx0 : 0u) << rp.g_shift)) * 3;
     for (uint32_t c0 = 0; c0 < rp.chunks; c0 += G, p += ((size_t)cam.W << rp.g_shift) * 3) {
         const uint32_t n = rp.chunks - c0 < G ? rp.chunks - c0 : G;
-        for (uint32_t k = 0; k < n; ++k) acc = acc + V3<R>{p[3 * k], p[3 * k + 1], p[3 * k + 2]};
+        for (uint32_t c1 = 0; c1 < n; c1 += TC) {
+            const uint32_t m = n - c1 < TC ? n - c1 : TC, m3 = m * 3u, count = nvalid * m3;
+            __syncthreads(); /* the adds of the previous group are done with the tile */
+            for (uint32_t e = lane; e < count; e += MIRT_WAVE) {
+                const uint32_t j = m == TC ? e / (TC * 3u) : e / m3, r = e - j * m3;
+                tile[j * STRIDE + r] = p[((size_t)j * G + c1) * 3 + r];
+            }
+            __syncthreads();
+            if (valid)
+                for (uint32_t k = 0; k < m; ++k) acc = acc + V3<R>{tile[lane * STRIDE + 3 * k], tile[lane * STRIDE + 3 * k + 1], tile[lane * STRIDE + 3 * k + 2]};
+        }
     }
+    if (!valid) return;
+    (void)n_pixels;
     if (accum) {
         accum[o] = acc.x;
         accum[o + 1] = acc.y;
