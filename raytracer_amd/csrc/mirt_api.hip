@@ -1004,10 +1004,21 @@ int mirt_deinterleave_device(const void* d_bands, size_t band_stride_bytes, uint
     if (total == 0) return MIRT_OK;
     size_t need = (size_t)part_rows(height, strip_rows, 0, part_count) * width * elem_bytes;
     if (band_stride_bytes < need) return fail(MIRT_ERR_INVALID, "band_stride_bytes smaller than the largest band");
-    size_t grid = (total + 255) / 256;
+    const size_t row_bytes = (size_t)width * elem_bytes;
+    const uintptr_t mis = (uintptr_t)d_bands | (uintptr_t)d_frame | (uintptr_t)row_bytes | (uintptr_t)band_stride_bytes;
+    const size_t unit = (mis % 16 == 0) ? 16 : (mis % 4 == 0) ? 4 : 1;
+    size_t grid = (total / unit + 255) / 256;
     if (grid > 0x7FFFFFFFull) return fail(MIRT_ERR_TOO_LARGE, "frame too large");
-    hipLaunchKernelGGL(deinterleave_kernel, dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_bands, band_stride_bytes,
-                       part_count, strip_rows, width, height, elem_bytes, (uint8_t*)d_frame);
+    hipStream_t st = (hipStream_t)stream;
+    if (unit == 16)
+        hipLaunchKernelGGL(deinterleave_kernel<uint4>, dim3((uint32_t)grid), dim3(256), 0, st, (const uint4*)d_bands, band_stride_bytes / 16, part_count, strip_rows,
+                           row_bytes / 16, height, (uint4*)d_frame);
+    else if (unit == 4)
+        hipLaunchKernelGGL(deinterleave_kernel<uint32_t>, dim3((uint32_t)grid), dim3(256), 0, st, (const uint32_t*)d_bands, band_stride_bytes / 4, part_count,
+                           strip_rows, row_bytes / 4, height, (uint32_t*)d_frame);
+    else
+        hipLaunchKernelGGL(deinterleave_kernel<uint8_t>, dim3((uint32_t)grid), dim3(256), 0, st, (const uint8_t*)d_bands, band_stride_bytes, part_count, strip_rows,
+                           row_bytes, height, (uint8_t*)d_frame);
     HIP_TRY(hipGetLastError());
     return MIRT_OK;
 }

@@ -1610,20 +1610,21 @@ template <class R> __global__ void quantize_kernel(const R* __restrict__ lin, si
     if (nan && nan_count) atomicAdd(nan_count, 1ull);
 }
 
-/* ---- K4: gathered bands -> frame.  One thread per 4 bytes where possible. --------------------------- */
-__global__ void deinterleave_kernel(const uint8_t* __restrict__ bands, size_t band_stride, uint32_t part_count, uint32_t strip_rows,
-                                    uint32_t width, uint32_t height, uint32_t elem_bytes, uint8_t* __restrict__ frame) {
-    size_t row_bytes = (size_t)width * elem_bytes;
-    size_t total = row_bytes * height;
+/* ---- K4: gathered bands -> frame.  One thread per unit of 16, 4 or 1 bytes: the widest that divides a row and the band
+ *      stride and matches the pointers' alignment (chosen by the host). ------------------------------------------------ */
+template <class U>
+__global__ void deinterleave_kernel(const U* __restrict__ bands, size_t band_stride, uint32_t part_count, uint32_t strip_rows,
+                                    size_t row_units, uint32_t height, U* __restrict__ frame) { /* band_stride and row_units in units of U */
+    size_t total = row_units * height;
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= total) return;
-    uint32_t gy = (uint32_t)(i / row_bytes);
-    size_t in_row = i - (size_t)gy * row_bytes;
+    uint32_t gy = (uint32_t)(i / row_units);
+    size_t in_row = i - (size_t)gy * row_units;
     uint32_t strip = gy / strip_rows, within = gy - strip * strip_rows;
     uint32_t part = strip % part_count, ls = strip / part_count;
     /* rows of earlier local strips are all full strips (only the last global strip can be short) */
     size_t lr = (size_t)ls * strip_rows + within;
-    frame[i] = bands[(size_t)part * band_stride + lr * row_bytes + in_row];
+    frame[i] = bands[(size_t)part * band_stride + lr * row_units + in_row];
 }
 
 } /* namespace mirt */

@@ -498,3 +498,26 @@ def test_fuzz_radiance_against_the_oracle():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_radiance.py"), "7000", "12"], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode == 0 and "failing renders: 0" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
+
+
+@pytest.mark.parametrize("width,elem", [(72, 12), (72, 3), (71, 3), (71, 12), (5, 24), (1920, 12), (64, 1)])
+def test_deinterleave_unit_sizes(width, elem):
+    """K4 moves 16-, 4- or 1-byte units depending on the row size and the alignment; every choice is the host scatter."""
+    import torch
+
+    from raytracer_amd import dist
+
+    lib = abi.load()
+    H, S = 43, 8
+    rng = np.random.default_rng(width * 31 + elem)
+    for n in (1, 3):
+        rows0 = dist.part_rows(H, S, 0, n)
+        bands = rng.integers(0, 256, (n, rows0, width, elem), dtype=np.uint8)
+        want = dist.deinterleave_host(bands, H, S)
+        d_bands = torch.from_numpy(bands).cuda()
+        for off in (0, 4 if (width * elem) % 4 == 0 else 1):  # a frame pointer that is not 16-byte aligned falls back to narrower units
+            buf = torch.zeros(H * width * elem + 16, dtype=torch.uint8, device="cuda")
+            abi.check(lib.mirt_deinterleave_device(d_bands.data_ptr(), rows0 * width * elem, n, S, width, H, elem, buf.data_ptr() + off, None))
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy()[off : off + H * width * elem].reshape(H, width, elem)
+            assert np.array_equal(got, want)
