@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Frames in flight: an 1/PARTS band of the bench frame (one rank's share), rendered FRAMES times
  (a) back to back on one stream, one scene handle;
- (b) alternating between two scene handles on two streams (each handle owns its work queue and partial sums),
+ (b) alternating between two (three, four) scene handles on as many streams (each handle owns its work queue and partial sums),
      so the next frame's blocks take the CUs the last long paths of the previous frame leave idle.
 usage: tools/inflight_probe.py [PARTS [FRAMES]]"""
 import ctypes as C, os, sys, time
@@ -16,12 +16,12 @@ frames = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 lib = abi.load()
 scene, cam, name = bench.build_workload("balls1080p", 1920, 64, 50)
 S = dist.DEFAULT_STRIP_ROWS
-handles = [DeviceScene(scene.flat, 0), DeviceScene(scene.flat, 0)]
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+handles = [DeviceScene(scene.flat, 0) for _ in range(4)]
+streams = [torch.cuda.Stream() for _ in range(4)]
 for rank in sorted({0, parts // 2, parts - 1}):
     rows = dist.part_rows(cam.height, S, rank, parts)
-    bands = [torch.zeros((rows, cam.width, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
-    bands8 = [torch.zeros((rows, cam.width, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    bands = [torch.zeros((rows, cam.width, 3), dtype=torch.float32, device="cuda") for _ in range(4)]
+    bands8 = [torch.zeros((rows, cam.width, 3), dtype=torch.uint8, device="cuda") for _ in range(4)]
     opts = cam.opts(precision=32, seed=1, strip_rows=S, part_index=rank, part_count=parts, flags=abi.FLAG_COMPACT_ROWS)
 
     def run(nh):
@@ -36,6 +36,6 @@ for rank in sorted({0, parts // 2, parts - 1}):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / frames * 1e3
 
-    a, b = run(1), run(2)
-    same = bool(torch.equal(bands[0], bands[1]))
-    print(f"part {rank}/{parts}: {rows} rows  one stream {a:.3f} ms/frame   two in flight {b:.3f} ms/frame   frames identical: {same}", flush=True)
+    t = [run(k) for k in (1, 2, 3, 4)]
+    same = all(bool(torch.equal(bands[0], bands[k])) for k in (1, 2, 3))
+    print(f"part {rank}/{parts}: {rows} rows  ms/frame with 1 / 2 / 3 / 4 frames in flight: " + " / ".join(f"{x:.3f}" for x in t) + f"   frames identical: {same}", flush=True)
