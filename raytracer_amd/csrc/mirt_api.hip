@@ -467,7 +467,10 @@ static int launch_primary(const mirt_scene* s, const SceneBuffers<float>& b, con
 /* Samples per work item.  A lane runs the samples of its item back to back, so the launch cannot end before its
  * longest item has: samples of one pixel are correlated (all 64 samples of a pixel on a glass ball bounce to the depth
  * limit), and with 4 samples per item the tail of a 1/8-frame band (the 8-GPU share) was 2.5 ms against 1.5 ms with
- * one.  So: as few samples per item as the partial-sum workspace allows (12 B per item in f32). */
+ * one.  So: as few samples per item as the partial-sum workspace allows (12 B per item in f32).
+ * n_pixels is the pixel count of the WHOLE frame, whatever part of it a call renders: a pixel's radiance is the sum, in
+ * chunk order, of per-chunk sums, so its last bits depend on the chunk size - and the image must not depend on how many
+ * GPUs share the frame (tests/test_gpu_parity.py::test_bench_frame_full_size_properties). */
 #define MIRT_PARTIAL_BUDGET (1024ull << 20)
 static void choose_chunks(uint64_t n_pixels, uint32_t nsamples, size_t real_bytes, uint32_t* chunk, uint32_t* chunks) {
     uint64_t max_chunks = MIRT_PARTIAL_BUDGET / (std::max<uint64_t>(n_pixels, 1) * 3 * real_bytes);
@@ -509,7 +512,7 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     if (n_pixels == 0) return MIRT_OK;
     RenderParams rp;
     rp.nsamples = cam->samples_per_pixel ? cam->samples_per_pixel : 1u;
-    choose_chunks(n_pixels, rp.nsamples, sizeof(R), &rp.chunk, &rp.chunks);
+    choose_chunks((uint64_t)cam->img_width * cam->img_height, rp.nsamples, sizeof(R), &rp.chunk, &rp.chunks);
     /* a progressive pass renders whole chunks [first / Q, (first + count) / Q) of the same decomposition the one-call render uses */
     rp.chunk_first = 0;
     rp.norm_samples = rp.nsamples;
@@ -773,7 +776,7 @@ uint32_t mirt_pass_granularity(const mirt_camera* cam, const mirt_opts* o) {
     DevPart part;
     if (make_part(cam, o, &part)) return 0;
     uint32_t chunk = 1, chunks = 1;
-    choose_chunks((uint64_t)cam->img_width * part.local_rows, cam->samples_per_pixel, o->precision == MIRT_F64 ? 8 : 4, &chunk, &chunks);
+    choose_chunks((uint64_t)cam->img_width * cam->img_height, cam->samples_per_pixel, o->precision == MIRT_F64 ? 8 : 4, &chunk, &chunks);
     return chunk;
 }
 /* diagnostic builds (-DMIRT_VERIFY_BROAD, -DMIRT_PHASE_TIMING, ...): what the kernels counted, on stderr */

@@ -521,3 +521,61 @@ def test_deinterleave_unit_sizes(width, elem):
             torch.cuda.synchronize()
             got = buf.cpu().numpy()[off : off + H * width * elem].reshape(H, width, elem)
             assert np.array_equal(got, want)
+
+
+def test_bench_frame_full_size_properties(scenes):
+    """BASELINE's configuration (1920x1080, 64 spp, depth 50, ~485 spheres) is too large for the oracle; at that size the
+    frame is checked through properties that do not depend on the size: the 8 interleaved bands of an 8-GPU run,
+    reassembled by K4, are the one-call frame bit for bit (linear radiance and bytes, equal segment counts); so is the
+    frame accumulated in two progressive passes; so is the frame of the vector-ALU broad phase; a second run repeats it."""
+    import torch
+
+    from raytracer_amd import dist
+
+    lib = abi.load()
+    sc = scenes["balls"]
+    cam = presets.bouncing_balls_camera(1920, 64, 50)
+    ds = sc.device_scene(0)
+    H, W, S, n = cam.height, cam.width, 8, 8
+    assert (H, W) == (1080, 1920)
+
+    def whole(flags=0):
+        lin = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        st = abi.MirtStats()
+        o = cam.opts(precision=abi.F32, seed=1, flags=flags)
+        abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(o), lin.data_ptr(), rgb.data_ptr(), None, C.byref(st)))
+        return lin, rgb, st.segments
+
+    ref, ref8, seg_ref = whole()
+    again, again8, seg2 = whole()
+    assert torch.equal(ref, again) and torch.equal(ref8, again8) and seg2 == seg_ref and seg_ref > 2 * H * W * 64 * 0.9
+    valu, valu8, seg3 = whole(abi.FLAG_VALU_BROAD)
+    assert torch.equal(ref, valu) and torch.equal(ref8, valu8) and seg3 == seg_ref
+    # 8 bands -> K4
+    rows0 = dist.part_rows(H, S, 0, n)
+    bands = torch.zeros((n, rows0, W, 3), dtype=torch.float32, device="cuda")
+    bands8 = torch.zeros((n, rows0, W, 3), dtype=torch.uint8, device="cuda")
+    seg = 0
+    for r in range(n):
+        o = cam.opts(precision=abi.F32, seed=1, strip_rows=S, part_index=r, part_count=n, flags=abi.FLAG_COMPACT_ROWS)
+        st = abi.MirtStats()
+        abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(o), bands[r].data_ptr(), bands8[r].data_ptr(), None, C.byref(st)))
+        seg += st.segments
+    frame = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    frame8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+    abi.check(lib.mirt_deinterleave_device(bands.data_ptr(), bands[0].numel() * 4, n, S, W, H, 12, frame.data_ptr(), None))
+    abi.check(lib.mirt_deinterleave_device(bands8.data_ptr(), bands8[0].numel(), n, S, W, H, 3, frame8.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(frame, ref) and torch.equal(frame8, ref8) and seg == seg_ref
+    # two progressive passes
+    acc = torch.full((H, W, 3), float("nan"), dtype=torch.float32, device="cuda")
+    lin = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    o = cam.opts(precision=abi.F32, seed=1)
+    g = lib.mirt_pass_granularity(C.byref(cam.pod), C.byref(o))
+    assert g >= 1 and 64 % g == 0
+    for first, count in ((0, 24 // g * g), (24 // g * g, 64 - 24 // g * g)):
+        abi.check(lib.mirt_render_pass_device(ds.handle, C.byref(cam.pod), C.byref(o), first, count, acc.data_ptr(), lin.data_ptr(), rgb.data_ptr(), None, None))
+    torch.cuda.synchronize()
+    assert torch.equal(lin, ref) and torch.equal(rgb, ref8)
