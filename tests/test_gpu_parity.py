@@ -544,7 +544,7 @@ def test_bench_frame_full_size_properties(scenes, workload):
         sc, cam, spp = presets.textured_scene(), presets.textured_camera(3840, 256, 50), 256
         assert (cam.height, cam.width) == (2160, 3840)
     ds = sc.device_scene(0)
-    H, W, S, n = cam.height, cam.width, 8, 8
+    H, W = cam.height, cam.width
 
     def whole(flags=0):
         lin = torch.zeros((H, W, 3), dtype=real, device="cuda")
@@ -559,22 +559,24 @@ def test_bench_frame_full_size_properties(scenes, workload):
     assert torch.equal(ref, again) and torch.equal(ref8, again8) and seg2 == seg_ref and seg_ref > 1.5 * H * W * spp
     valu, valu8, seg3 = whole(abi.FLAG_VALU_BROAD)
     assert torch.equal(ref, valu) and torch.equal(ref8, valu8) and seg3 == seg_ref
-    # 8 bands -> K4
-    rows0 = dist.part_rows(H, S, 0, n)
-    bands = torch.zeros((n, rows0, W, 3), dtype=real, device="cuda")
-    bands8 = torch.zeros((n, rows0, W, 3), dtype=torch.uint8, device="cuda")
-    seg = 0
-    for r in range(n):
-        o = cam.opts(precision=prec, seed=1, strip_rows=S, part_index=r, part_count=n, flags=abi.FLAG_COMPACT_ROWS)
-        st = abi.MirtStats()
-        abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(o), bands[r].data_ptr(), bands8[r].data_ptr(), None, C.byref(st)))
-        seg += st.segments
-    frame = torch.empty((H, W, 3), dtype=real, device="cuda")
-    frame8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
-    abi.check(lib.mirt_deinterleave_device(bands.data_ptr(), bands[0].numel() * rsz, n, S, W, H, 3 * rsz, frame.data_ptr(), None))
-    abi.check(lib.mirt_deinterleave_device(bands8.data_ptr(), bands8[0].numel(), n, S, W, H, 3, frame8.data_ptr(), None))
-    torch.cuda.synchronize()
-    assert torch.equal(frame, ref) and torch.equal(frame8, ref8) and seg == seg_ref
+    # bands -> K4: the 8-GPU split of bench.py, and (bench frame) other rank counts and strip heights
+    for n, S in ((8, 8),) + (((2, 8), (4, 16), (3, 5)) if workload == "balls-f32" else ()):
+        rows0 = dist.part_rows(H, S, 0, n)
+        bands = torch.zeros((n, rows0, W, 3), dtype=real, device="cuda")
+        bands8 = torch.zeros((n, rows0, W, 3), dtype=torch.uint8, device="cuda")
+        seg = 0
+        for r in range(n):
+            o = cam.opts(precision=prec, seed=1, strip_rows=S, part_index=r, part_count=n, flags=abi.FLAG_COMPACT_ROWS)
+            st = abi.MirtStats()
+            abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(o), bands[r].data_ptr(), bands8[r].data_ptr(), None, C.byref(st)))
+            seg += st.segments
+        frame = torch.empty((H, W, 3), dtype=real, device="cuda")
+        frame8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+        abi.check(lib.mirt_deinterleave_device(bands.data_ptr(), bands[0].numel() * rsz, n, S, W, H, 3 * rsz, frame.data_ptr(), None))
+        abi.check(lib.mirt_deinterleave_device(bands8.data_ptr(), bands8[0].numel(), n, S, W, H, 3, frame8.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert torch.equal(frame, ref) and torch.equal(frame8, ref8) and seg == seg_ref, (n, S)
+        del bands, bands8, frame, frame8
     # two progressive passes
     acc = torch.full((H, W, 3), float("nan"), dtype=real, device="cuda")
     lin = torch.zeros((H, W, 3), dtype=real, device="cuda")
@@ -611,3 +613,19 @@ def test_stress_frame_full_size_front_ends_agree():
     for name in ("valu", "tree"):
         assert torch.equal(out[name][0], out["matrix"][0]) and torch.equal(out[name][1], out["matrix"][1]) and out[name][2] == out["matrix"][2], name
     assert out["matrix"][2] > H * W * 16
+
+
+def test_hundred_thousand_spheres_front_ends_agree():
+    """The largest stress scene of BASELINE (100 000 spheres; brute force streams 3 MB of operands per wave and segment) at a
+    reduced frame size: matrix-pipe loop, vector-ALU loop and tree give the same maps and the same rendered frame."""
+    sc = presets.stress_scene(100000, 1)
+    cam = presets.stress_camera(256, 0, 50)
+    maps = {a: cam.primary_hits(sc, precision=abi.F32, accel=a) for a in (None, "valu", "bvh")}
+    assert (maps[None][0] != abi.MISS_ID).mean() > 0.2
+    for a in ("valu", "bvh"):
+        assert np.array_equal(maps[a][0], maps[None][0]) and np.array_equal(maps[a][1].view(np.uint32), maps[None][1].view(np.uint32)), a
+    rcam = presets.stress_camera(160, 2, 12)
+    ref, ref8 = rcam.render_arrays(sc, precision=abi.F32, seed=3)
+    for a in ("valu", "bvh"):
+        lin, rgb8 = rcam.render_arrays(sc, precision=abi.F32, seed=3, accel=a)
+        assert np.array_equal(lin.view(np.uint32), ref.view(np.uint32)) and np.array_equal(rgb8, ref8), a
