@@ -629,3 +629,17 @@ def test_hundred_thousand_spheres_front_ends_agree():
     for a in ("valu", "bvh"):
         lin, rgb8 = rcam.render_arrays(sc, precision=abi.F32, seed=3, accel=a)
         assert np.array_equal(lin.view(np.uint32), ref.view(np.uint32)) and np.array_equal(rgb8, ref8), a
+
+
+@pytest.mark.parametrize("width,ratio", [(1, 1.0), (1, 1 / 7), (3, 3.0), (63, 21.0), (64, 64.0), (65, 65 / 3), (129, 64.5), (200, 0.9)])
+def test_render_odd_image_sizes_vs_oracle(oracle, scenes, width, ratio):
+    """Rows shorter than, equal to and just over a wave of the resolve kernel, single rows and single columns."""
+    sc = scenes["balls"]
+    cam = Camera.build((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), None, width, ratio, 5, math.radians(25.0), 10.0, math.radians(0.4), 8)
+    for prec, tol in ((abi.F64, 1e-9), (abi.F32, 2e-5)):
+        lin, rgb8 = cam.render_arrays(sc, precision=prec, seed=11)
+        o_lin, o_rgb8, o_seg, _ = oracle.render(sc.flat, cam.pod, prec, seed=11, threads=4)
+        assert lin.shape == o_lin.shape == (cam.height, cam.width, 3)
+        err = np.abs(lin.astype(np.float64) - o_lin.astype(np.float64))
+        assert float((err <= tol * (1.0 + np.abs(o_lin))).mean()) >= 0.99, (width, ratio, prec)
+        assert abs(cam.last_stats["segments"] - o_seg) <= max(16, 0.002 * o_seg)
