@@ -643,3 +643,16 @@ def test_render_odd_image_sizes_vs_oracle(oracle, scenes, width, ratio):
         err = np.abs(lin.astype(np.float64) - o_lin.astype(np.float64))
         assert float((err <= tol * (1.0 + np.abs(o_lin))).mean()) >= 0.99, (width, ratio, prec)
         assert abs(cam.last_stats["segments"] - o_seg) <= max(16, 0.002 * o_seg)
+
+
+def test_many_samples_few_pixels_vs_oracle(oracle, scenes):
+    """777 samples per pixel on a 12x7 image: many chunks per pixel, several passes of the queue order, a last pass that is
+    not full; the sums are added in sample order on both sides."""
+    sc = scenes["balls"]
+    cam = Camera.build((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), None, 12, 12 / 7, 777, math.radians(25.0), 10.0, math.radians(0.4), 6)
+    for prec, tol in ((abi.F64, 1e-9), (abi.F32, 2e-5)):
+        lin, _ = cam.render_arrays(sc, precision=prec, seed=21)
+        o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, prec, seed=21, threads=8)
+        err = np.abs(lin.astype(np.float64) - o_lin.astype(np.float64))
+        assert float((err <= tol * (1.0 + np.abs(o_lin))).mean()) >= 0.97 and err.max() < 0.02, (prec, err.max())
+        assert abs(cam.last_stats["segments"] - o_seg) <= 0.002 * o_seg
