@@ -656,3 +656,28 @@ def test_many_samples_few_pixels_vs_oracle(oracle, scenes):
         err = np.abs(lin.astype(np.float64) - o_lin.astype(np.float64))
         assert float((err <= tol * (1.0 + np.abs(o_lin))).mean()) >= 0.97 and err.max() < 0.02, (prec, err.max())
         assert abs(cam.last_stats["segments"] - o_seg) <= 0.002 * o_seg
+
+
+@pytest.mark.parametrize("n", [641, 800, 1100])
+def test_more_materials_than_the_lds_table_holds(oracle, n):
+    """One material per sphere: beyond 640 materials the matrix-pipe kernel reads material records from HBM/L2 instead of
+    its LDS copy (and beyond 1024 spheres everything streams); radiance against the oracle either way."""
+    rng = np.random.default_rng(n)
+    sc = Scene()
+    sc.add(Sphere.new_static(300.0, (0.0, -300.0, 0.0), Lambertian.with_texture(CheckerTexture(0.7, (0.2, 0.3, 0.1), (0.9, 0.9, 0.9)), 0.8)))
+    for k in range(n - 1):
+        c = rng.uniform(-9, 9, 3) * np.array([1.0, 0.0, 1.0]) + np.array([0.0, 0.25, 0.0])
+        kind = k % 3
+        m = (Lambertian.new(tuple(rng.uniform(0.1, 0.9, 3)), float(rng.uniform(0.5, 1.0))) if kind == 0
+             else Metal.new(tuple(rng.uniform(0.4, 1.0, 3)), float(rng.uniform(0.0, 0.5))) if kind == 1 else Dielectric.new(float(rng.uniform(1.2, 1.9))))
+        sc.add(Sphere.new_static(0.25, tuple(c), m))
+    sc.build_bvh()
+    cam = Camera.build((12.0, 3.0, 4.0), (0.0, 0.0, 0.0), None, 96, 1.6, 6, math.radians(35.0), 12.0, math.radians(0.3), 10)
+    assert cam.closest_hit_kind(sc, precision=abi.F32) == "matrix"
+    for prec, tol in ((abi.F64, 1e-9), (abi.F32, 2e-5)):
+        o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, prec, seed=4, threads=8)
+        for accel in (None, "valu"):
+            lin, _ = cam.render_arrays(sc, precision=prec, seed=4, accel=accel)
+            err = np.abs(lin.astype(np.float64) - o_lin.astype(np.float64))
+            assert float((err <= tol * (1.0 + np.abs(o_lin))).mean()) >= 0.995, (prec, accel)
+            assert abs(cam.last_stats["segments"] - o_seg) <= max(20, 0.002 * o_seg)
