@@ -681,3 +681,17 @@ def test_more_materials_than_the_lds_table_holds(oracle, n):
             err = np.abs(lin.astype(np.float64) - o_lin.astype(np.float64))
             assert float((err <= tol * (1.0 + np.abs(o_lin))).mean()) >= 0.995, (prec, accel)
             assert abs(cam.last_stats["segments"] - o_seg) <= max(20, 0.002 * o_seg)
+
+
+def test_render_empty_scene_is_the_sky(oracle):
+    """No spheres: every path is one segment into the sky gradient (camera.rs:282-284), through every front end."""
+    sc = Scene()
+    sc.build_bvh()
+    cam = _cam(w=40, ratio=1.5, spp=3, depth=5)
+    for prec, tol in ((abi.F64, 1e-12), (abi.F32, 1e-6)):
+        o_lin, o_rgb8, o_seg, _ = oracle.render(sc.flat, cam.pod, prec, seed=2, threads=2)
+        assert o_seg == cam.height * cam.width * 3
+        for accel in (None, "valu") + (("bvh",) if prec == abi.F32 else ()):
+            lin, rgb8 = cam.render_arrays(sc, precision=prec, seed=2, accel=accel)
+            assert np.abs(lin.astype(np.float64) - o_lin.astype(np.float64)).max() <= tol and np.array_equal(rgb8, o_rgb8), (prec, accel)
+            assert cam.last_stats["segments"] == o_seg
