@@ -217,7 +217,9 @@ int mirt_render_pass_device(const mirt_scene* scene, const mirt_camera* cam, con
 int mirt_render_pass(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
                      uint32_t first_sample, uint32_t sample_count, void* accum,
                      void* rgb_linear, uint8_t* rgb8, mirt_stats* stats);
-/* Samples per work item for this image and partition (1, 2, 4, ...): the unit of pass boundaries.  0 = no anti-aliasing. */
+/* Samples per work item for this image (1, 2, 4, ...): the unit of pass boundaries.  It follows from the size of the
+ * whole frame and the sample count, not from the part a call renders: a pixel's radiance is a sum of per-item sums, so
+ * its last bits depend on this size, and the image does not depend on the partition.  0 = no anti-aliasing. */
 uint32_t mirt_pass_granularity(const mirt_camera* cam, const mirt_opts* opts);
 
 /* K4: scatter `part_count` compact bands (as gathered with RCCL, band r at
