@@ -695,3 +695,15 @@ def test_render_empty_scene_is_the_sky(oracle):
             lin, rgb8 = cam.render_arrays(sc, precision=prec, seed=2, accel=accel)
             assert np.abs(lin.astype(np.float64) - o_lin.astype(np.float64)).max() <= tol and np.array_equal(rgb8, o_rgb8), (prec, accel)
             assert cam.last_stats["segments"] == o_seg
+
+
+def test_fuzz_partitions_and_passes():
+    """A slice of tools/fuzz_partition.py (run over 5 400 cases): random sizes, sample counts, rank counts, strip heights, pass
+    cuts and queue knobs - bands and passes assemble into the one-call frame bit for bit."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_partition.py"), "9000", "40"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0 and "mismatching frames: 0" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
