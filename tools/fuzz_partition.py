@@ -1,7 +1,7 @@
 """Fuzz of the work decomposition: random image sizes, sample counts, rank counts, strip heights, pass cuts, queue-order
 and work-item knobs - the frame assembled from bands and progressive passes must be the one-call frame bit for bit
 (linear radiance, bytes, segment count), in both precisions and through every front end.
-usage: PYTHONPATH=. python tools/fuzz_partition.py [first_seed] [n_cases]"""
+usage: PYTHONPATH=. python tools/fuzz_partition.py [first_seed] [n_cases]      (FUZZ_MAX_W / FUZZ_MAX_SPP: larger frames)"""
 import ctypes as C
 import os
 import sys
@@ -26,7 +26,7 @@ for case in range(n_cases):
         os.environ["MIRT_GROUP_CHUNKS"] = str(int(rng.choice([1, 2, 4, 16, 64])))
     name = "balls" if rng.random() < 0.8 else "mars"
     sc = scenes[name]
-    W, spp, depth = int(rng.integers(1, 260)), int(rng.integers(1, 40)), int(rng.integers(1, 12))
+    W, spp, depth = int(rng.integers(1, int(os.environ.get("FUZZ_MAX_W", "260")))), int(rng.integers(1, int(os.environ.get("FUZZ_MAX_SPP", "40")))), int(rng.integers(1, 12))
     cam = (presets.bouncing_balls_camera if name == "balls" else presets.default_camera)(W, spp, depth)
     H = cam.height
     prec = abi.F64 if rng.random() < 0.3 else abi.F32
