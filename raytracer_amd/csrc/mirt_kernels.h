@@ -907,19 +907,30 @@ template <class R, class G> __device__ inline Hit<R> make_hit(const DevScene<R>&
 }
 
 /* ---- closest-hit front ends used by the kernels: f64 = exact broad phase, f32 = conservative broad phase ---- */
+#define MIRT_TINY_SCENE 8u /* sorted slots (padded to groups of 4) */
 struct TracerF64 {
     typedef double Real;
     static constexpr bool RESUMABLE = false;
     const DevScene<double>& sc;
     WaveLds<double>& lds;
     __device__ inline void closest(uint32_t lane, bool active, const RayT<double>& ray, double tmin, Closest<double>& best, uint32_t& nc, PhaseTimer& pt) {
+        if (sc.n <= MIRT_TINY_SCENE) { /* a handful of spheres: the exact test on each (see TracerF32::closest) */
+            best.t = (double)INFINITY;
+            best.idx = 0xFFFFFFFFu;
+            const double a = ray_a(ray.d);
+            if (active) {
+                for (uint32_t i = 0; i < sc.n; ++i) narrow_test(sc, GeomGlobal<double>{sc}, i, ray, a, tmin, best); /* dummy records never hit */
+                nc += sc.n;
+            }
+            pt.stamp(PH_NARROW);
+            return;
+        }
         trace<double, true>(sc, lds, lane, active, ray, tmin, best, nc, pt);
     }
     __device__ inline Hit<double> hit(const Closest<double>& c, const RayT<double>& ray) const { return make_hit(sc, GeomGlobal<double>{sc}, c, ray); }
     __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }
     __device__ inline const DevMaterial<double>& material_record(uint32_t idx) const { return sc.mats[material(idx)]; }
 };
-#define MIRT_TINY_SCENE 8u /* sorted slots (padded to groups of 4) */
 template <bool RES> struct TracerF32 {
     typedef float Real;
     static constexpr bool RESUMABLE = false;
