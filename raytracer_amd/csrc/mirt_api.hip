@@ -266,8 +266,10 @@ static int upload_real(mirt_scene* s, const mirt_scene_desc* d, const std::vecto
             o.tex_kind = t.kind;
             o.inv_scale = (R)t.inv_scale;
             if (t.kind != MIRT_TEX_IMAGE) {
-                o.albedo = {(R)t.color[0], (R)t.color[1], (R)t.color[2]};
-                o.odd = {(R)t.odd[0], (R)t.odd[1], (R)t.odd[2]};
+                /* a surviving bounce carries colour / reflectance (material.rs:78): for constant colours the quotient is taken
+                 * here, once, in the kernels' precision - the same IEEE division the kernel would repeat at every bounce */
+                o.albedo = {(R)t.color[0] / o.reflectance, (R)t.color[1] / o.reflectance, (R)t.color[2] / o.reflectance};
+                o.odd = {(R)t.odd[0] / o.reflectance, (R)t.odd[1] / o.reflectance, (R)t.odd[2] / o.reflectance};
             } else {
                 o.img_w = imgs[t.image].w; o.img_h = imgs[t.image].h; o.img_offset = imgs[t.image].offset;
             }

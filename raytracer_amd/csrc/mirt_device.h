@@ -81,8 +81,8 @@ template <class R> struct DevMaterial {
     uint32_t kind, tex_kind, has_fuzz, img_w; /* tex_kind: LAMBERTIAN only */
     uint32_t img_h, img_offset, _pad0, _pad1; /* IMAGE texture: size, first texel in the pool (img_h == 0: cyan, texture.rs:78-80) */
     R reflectance, fuzz, ior, inv_scale;
-    V3<R> albedo; /* METAL albedo | SOLID colour | CHECKER even colour */
-    V3<R> odd;    /* CHECKER odd colour */
+    V3<R> albedo; /* METAL albedo | SOLID colour / reflectance | CHECKER even colour / reflectance (the attenuation of material.rs:78) */
+    V3<R> odd;    /* CHECKER odd colour / reflectance */
 };
 /* Node of the bounding-volume tree (MIRT_FLAG_BVH): the boxes of BOTH children, one 64-byte fetch per step.
  *   q0 = (lo0.x, lo0.y, lo0.z, hi0.x)  q1 = (hi0.y, hi0.z, lo1.x, lo1.y)  q2 = (lo1.z, hi1.x, hi1.y, hi1.z)

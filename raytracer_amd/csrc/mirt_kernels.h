@@ -1034,7 +1034,9 @@ template <class R> __device__ inline uint32_t to_u32_sat(R x) { /* Rust `as u32`
     if (x >= (R)4294967295.0) return 0xFFFFFFFFu;
     return (uint32_t)x;
 }
-template <class R> __device__ inline V3<R> texture_color(const DevScene<R>& sc, const DevMaterial<R>& m, const Hit<R>& h) {
+/* Lambertian attenuation = texture colour / reflectance (material.rs:78).  The constant colours come pre-divided from
+ * mirt_scene_create (same IEEE quotient); a texel is divided here. */
+template <class R> __device__ inline V3<R> lambertian_attenuation(const DevScene<R>& sc, const DevMaterial<R>& m, const Hit<R>& h) {
     if (m.tex_kind == MIRT_TEX_SOLID) return m.albedo; /* texture.rs:24-28 */
     if (m.tex_kind == MIRT_TEX_CHECKER) {              /* texture.rs:46-59 */
         uint32_t acc = (uint32_t)floor_to_i32(m_floor(h.p.x * m.inv_scale));
@@ -1043,7 +1045,7 @@ template <class R> __device__ inline V3<R> texture_color(const DevScene<R>& sc, 
         return (((int32_t)acc) % 2 == 0) ? m.albedo : m.odd;
     }
     /* IMAGE: texture.rs:71-94 with (u,v) of sphere.rs:72-76 */
-    if (m.img_h == 0) return {(R)0.0, (R)1.0, (R)1.0};
+    if (m.img_h == 0) return V3<R>{(R)0.0, (R)1.0, (R)1.0} / m.reflectance;
     const R PI = (R)3.14159265358979323846264338327950288;
     const R FRAC_1_PI = (R)0.318309886183790671537767526745028724;
     R theta = -m_acos(h.on.y);
@@ -1058,7 +1060,7 @@ template <class R> __device__ inline V3<R> texture_color(const DevScene<R>& sc, 
     i = i < m.img_w - 1 ? i : m.img_w - 1;
     j = j < m.img_h - 1 ? j : m.img_h - 1;
     uint32_t px = sc.texels[m.img_offset + j * m.img_w + i];
-    return {(R)(px & 0xFFu) / (R)255.0, (R)((px >> 8) & 0xFFu) / (R)255.0, (R)((px >> 16) & 0xFFu) / (R)255.0};
+    return V3<R>{(R)(px & 0xFFu) / (R)255.0, (R)((px >> 8) & 0xFFu) / (R)255.0, (R)((px >> 16) & 0xFFu) / (R)255.0} / m.reflectance;
 }
 
 /* ---- materials: scene/material.rs ----------------------------------------------------------------- */
@@ -1091,7 +1093,7 @@ __device__ inline bool scatter(const DevScene<R>& sc, const DevMaterial<R>& m, c
         const R e = (R)1e-8;
         if (m_fabs(dir.x) < e && m_fabs(dir.y) < e && m_fabs(dir.z) < e) dir = hit.n;
         out = {hit.p, dir, rin.tm};
-        att = texture_color(sc, m, hit) / m.reflectance;
+        att = lambertian_attenuation(sc, m, hit);
         return true;
     }
     if (m.kind == MIRT_MAT_METAL) { /* material.rs:97-114; dims 0..2 = vector */
