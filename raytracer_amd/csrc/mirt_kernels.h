@@ -1582,9 +1582,20 @@ __global__ __launch_bounds__(MIRT_RESOLVE_WAVES * MIRT_WAVE) void resolve_kernel
         for (uint32_t c1 = 0; c1 < n; c1 += TC) {
             const uint32_t m = n - c1 < TC ? n - c1 : TC, m3 = m * 3u, count = nvalid * m3;
             __syncthreads(); /* the adds of the previous group are done with the tile */
-            for (uint32_t e = lane; e < count; e += MIRT_WAVE) {
-                const uint32_t j = m == TC ? e / (TC * 3u) : e / m3, r = e - j * m3;
-                tile[j * STRIDE + r] = p[((size_t)j * G + c1) * 3 + r];
+            if (sizeof(R) == 4 && m == TC && rp.g_shift >= 2) {
+                /* full groups of f32 sums: 16-byte loads (a pixel's TC chunks are 6 aligned float4: slot numbers are multiples
+                 * of G >= 4 here, c1 of TC, and the workspace is a hipMalloc block) */
+                for (uint32_t e = lane; e < nvalid * (TC * 3u / 4u); e += MIRT_WAVE) {
+                    const uint32_t j = e / (TC * 3u / 4u), r = (e - j * (TC * 3u / 4u)) * 4u;
+                    const float4 v = *reinterpret_cast<const float4*>(p + ((size_t)j * G + c1) * 3 + r);
+                    R* d = tile + j * STRIDE + r;
+                    d[0] = (R)v.x; d[1] = (R)v.y; d[2] = (R)v.z; d[3] = (R)v.w;
+                }
+            } else {
+                for (uint32_t e = lane; e < count; e += MIRT_WAVE) {
+                    const uint32_t j = m == TC ? e / (TC * 3u) : e / m3, r = e - j * m3;
+                    tile[j * STRIDE + r] = p[((size_t)j * G + c1) * 3 + r];
+                }
             }
             __syncthreads();
             if (valid)
