@@ -62,6 +62,9 @@ struct mirt_scene {
     /* render workspace (per-item partial sums), grown on demand and kept until the scene is destroyed */
     mutable void* partial = nullptr;
     mutable size_t partial_bytes = 0;
+    /* device frames behind the host-buffer entry points (mirt_render / mirt_render_pass), grown on demand like `partial` */
+    mutable void* stage[3] = {nullptr, nullptr, nullptr};
+    mutable size_t stage_bytes[3] = {0, 0, 0};
     mutable hipEvent_t ev0 = nullptr, ev1 = nullptr; /* timing events of render calls that ask for statistics (created once) */
     /* MIRT_FLAG_DEFER_STATS: the counters land in pinned host memory behind the launch, mirt_render_wait reads them */
     mutable hipEvent_t ev2 = nullptr;
@@ -740,6 +743,7 @@ void mirt_scene_destroy(mirt_scene* s) {
     (void)hipSetDevice(s->device);
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->partial) (void)hipFree(s->partial);
+    for (void* p : s->stage) if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->ev2) (void)hipEventDestroy(s->ev2);
@@ -918,6 +922,17 @@ int mirt_primary_hits(const mirt_scene* s, const mirt_camera* cam, const mirt_op
     return rc;
 }
 
+/* slot k of the scene's staging frames, at least `need` bytes (nullptr + error set on failure) */
+static void* stage_frame(const mirt_scene* s, int k, size_t need) {
+    if (need > s->stage_bytes[k]) {
+        if (s->stage[k]) (void)hipFree(s->stage[k]);
+        s->stage[k] = nullptr;
+        s->stage_bytes[k] = 0;
+        if (hipMalloc(&s->stage[k], need) != hipSuccess) { (void)fail(MIRT_ERR_NOMEM, "hipMalloc failed"); return nullptr; }
+        s->stage_bytes[k] = need;
+    }
+    return s->stage[k];
+}
 int mirt_render(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, void* lin, uint8_t* rgb8, mirt_stats* stats) {
     int rc = check_common(s, cam, o);
     if (rc) return rc;
@@ -926,20 +941,19 @@ int mirt_render(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o,
     HIP_TRY(hipSetDevice(s->device));
     size_t n = (size_t)cam->img_width * cam->img_height * 3;
     size_t rsz = o->precision == MIRT_F64 ? 8 : 4;
-    void* d_lin = nullptr;
-    uint8_t* d_rgb8 = nullptr;
-    if (lin && hipMalloc(&d_lin, n * rsz) != hipSuccess) return fail(MIRT_ERR_NOMEM, "hipMalloc failed");
-    if (rgb8 && hipMalloc((void**)&d_rgb8, n) != hipSuccess) { (void)hipFree(d_lin); return fail(MIRT_ERR_NOMEM, "hipMalloc failed"); }
+    /* the device frames stay with the scene between calls (a hipMalloc + hipFree per frame cost more than the copy back) */
+    void* d_lin = lin ? stage_frame(s, 0, n * rsz) : nullptr;
+    uint8_t* d_rgb8 = rgb8 ? (uint8_t*)stage_frame(s, 1, n) : nullptr;
+    if ((lin && !d_lin) || (rgb8 && !d_rgb8)) return MIRT_ERR_NOMEM;
     rc = MIRT_OK;
-    if (d_lin && hipMemset(d_lin, 0, n * rsz) != hipSuccess) rc = fail(MIRT_ERR_HIP, "hipMemset failed");
-    if (!rc && d_rgb8 && hipMemset(d_rgb8, 0, n) != hipSuccess) rc = fail(MIRT_ERR_HIP, "hipMemset failed");
+    /* rows another part owns read as zero */
+    if (d_lin && hipMemsetAsync(d_lin, 0, n * rsz, nullptr) != hipSuccess) rc = fail(MIRT_ERR_HIP, "hipMemset failed");
+    if (!rc && d_rgb8 && hipMemsetAsync(d_rgb8, 0, n, nullptr) != hipSuccess) rc = fail(MIRT_ERR_HIP, "hipMemset failed");
     mirt_stats local;
     if (!rc) rc = mirt_render_device(s, cam, o, d_lin, d_rgb8, nullptr, &local);
     if (!rc && lin && hipMemcpy(lin, d_lin, n * rsz, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
     if (!rc && rgb8 && hipMemcpy(rgb8, d_rgb8, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
     if (!rc && stats) *stats = local;
-    (void)hipFree(d_lin);
-    (void)hipFree(d_rgb8);
     if (!rc && rgb8 && local.nan_pixels) return fail(MIRT_ERR_NAN, "a NaN reached the quantiser (the reference panics: rgb.rs:33)");
     return rc;
 }
@@ -953,11 +967,10 @@ int mirt_render_pass(const mirt_scene* s, const mirt_camera* cam, const mirt_opt
     if (!accum) return fail(MIRT_ERR_INVALID, "pass: the accumulation buffer is required");
     HIP_TRY(hipSetDevice(s->device));
     const size_t n = (size_t)cam->img_width * cam->img_height * 3, rsz = o->precision == MIRT_F64 ? 8 : 4;
-    void *d_acc = nullptr, *d_lin = nullptr;
-    uint8_t* d_rgb8 = nullptr;
-    if (hipMalloc(&d_acc, n * rsz) != hipSuccess) return fail(MIRT_ERR_NOMEM, "hipMalloc failed");
-    if (lin && hipMalloc(&d_lin, n * rsz) != hipSuccess) { (void)hipFree(d_acc); return fail(MIRT_ERR_NOMEM, "hipMalloc failed"); }
-    if (rgb8 && hipMalloc((void**)&d_rgb8, n) != hipSuccess) { (void)hipFree(d_acc); (void)hipFree(d_lin); return fail(MIRT_ERR_NOMEM, "hipMalloc failed"); }
+    void* d_acc = stage_frame(s, 2, n * rsz);
+    void* d_lin = lin ? stage_frame(s, 0, n * rsz) : nullptr;
+    uint8_t* d_rgb8 = rgb8 ? (uint8_t*)stage_frame(s, 1, n) : nullptr;
+    if (!d_acc || (lin && !d_lin) || (rgb8 && !d_rgb8)) return MIRT_ERR_NOMEM;
     rc = MIRT_OK;
     /* rows outside the part stay as the caller's accumulation has them */
     if (hipMemcpy(d_acc, accum, n * rsz, hipMemcpyHostToDevice) != hipSuccess) rc = fail(MIRT_ERR_HIP, "upload of the accumulation buffer failed");
@@ -969,9 +982,6 @@ int mirt_render_pass(const mirt_scene* s, const mirt_camera* cam, const mirt_opt
     if (!rc && lin && hipMemcpy(lin, d_lin, n * rsz, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
     if (!rc && rgb8 && hipMemcpy(rgb8, d_rgb8, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MIRT_ERR_HIP, "copy back failed");
     if (!rc && stats) *stats = local;
-    (void)hipFree(d_acc);
-    (void)hipFree(d_lin);
-    (void)hipFree(d_rgb8);
     if (!rc && rgb8 && local.nan_pixels) return fail(MIRT_ERR_NAN, "a NaN reached the quantiser (the reference panics: rgb.rs:33)");
     return rc;
 }
