@@ -477,6 +477,21 @@ class Camera:
             raise RenderError(f"WritePx: {e}") from e
 
 
+_DEC = np.zeros((256, 4), np.uint8)  # decimal digits of 0..255 followed by a separator slot, and their lengths
+_DEC_LEN = np.zeros(256, np.int64)
+for _v in range(256):
+    _d = str(_v).encode()
+    _DEC[_v, : len(_d)] = np.frombuffer(_d, np.uint8)
+    _DEC_LEN[_v] = len(_d)
+
+
 def ppm_body(rgb8: np.ndarray) -> bytes:
-    flat = rgb8.reshape(-1, 3)
-    return "".join(f"{r} {g} {b}\n" for r, g, b in flat.tolist()).encode()
+    """The "r g b\\n" lines of a frame (rgb.rs:28-36 through Display), vectorised: digits from a 256-entry table, a
+    separator after each value, the unused digit slots dropped."""
+    v = np.ascontiguousarray(rgb8, np.uint8).reshape(-1)
+    cells = _DEC[v].copy()  # (n, 4): up to three digits, then room for the separator
+    n = _DEC_LEN[v]
+    sep = np.where(np.arange(v.size) % 3 == 2, ord("\n"), ord(" ")).astype(np.uint8)
+    cells[np.arange(v.size), n] = sep
+    keep = np.arange(4)[None, :] <= n[:, None]
+    return cells[keep].tobytes()
