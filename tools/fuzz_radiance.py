@@ -41,7 +41,7 @@ for case in range(n_cases):
             return Metal.new(tuple(rng.uniform(0.3, 1.0, 3)), None if rng.random() < 0.3 else float(rng.uniform(0.0, 1.3)))
         return Dielectric.new(float(rng.uniform(1.05, 2.4)) if rng.random() < 0.8 else float(rng.uniform(0.4, 0.95)))
 
-    n = int(rng.integers(1, 140))
+    n = int(rng.integers(1, int(os.environ.get("FUZZ_MAX_N", "140"))))  # FUZZ_MAX_N=3000: beyond the LDS tables (640 materials, 1024 spheres)
     ext = float(rng.uniform(2.0, 12.0))
     sc = Scene()
     if rng.random() < 0.7:
@@ -49,7 +49,7 @@ for case in range(n_cases):
         sc.add(Sphere.new_static(R, (0.0, -R, 0.0), material()))
     for k in range(n):
         c = rng.uniform(-ext, ext, 3) * np.array([1.0, 0.3, 1.0]) + np.array([0.0, 0.3 * ext, 0.0])
-        r = float(rng.uniform(0.03, 0.25) * ext)
+        r = float(rng.uniform(0.03, 0.25) * ext) * min(1.0, (140.0 / max(n, 1)) ** 0.5)
         m = material()
         if rng.random() < 0.3:
             sc.add(Sphere.new(r, tuple(c), tuple(c + rng.uniform(-0.1, 0.1, 3) * ext), m))
