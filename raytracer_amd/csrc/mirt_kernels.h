@@ -543,7 +543,6 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
     uint32_t(*ent)[MIRT_WAVE] = L.ent[w];
     /* ---- the ray's operands ---- */
     mirt_h8 bgx, bgy, bex, bey;
-    uint32_t amask, omask;
     {
         const R inv = (R)1.0 / m_sqrt(a_true);
         const V3<float> Dn = {(float)(ray.d.x * inv), (float)(ray.d.y * inv), (float)(ray.d.z * inv)};
@@ -552,12 +551,19 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
         const float o2 = __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x));
         const float k2 = o2 * MIRT_MX_SHRINK - __builtin_fmaf(MIRT_MX_FLOOR_LIN, sqrtf(o2), MIRT_MX_FLOOR_ABS);
         const bool ok = o2 <= MIRT_MX_K2MAX; /* false for NaN */
-        amask = ok ? 0xFFFFFFFFu : 0xFFFF0000u; /* out of range: every sphere stays a candidate */
-        omask = active ? 0u : 0xFFFFu;          /* no ray: none */
         _Float16 dhx, dlx, dhy, dly, dhz, dlz, k1h, k1l, ohx, olx, ohy, oly, ohz, olz, k2h, k2l;
         mx_split(Dn.x, dhx, dlx); mx_split(Dn.y, dhy, dly); mx_split(Dn.z, dhz, dlz); mx_split(-k1, k1h, k1l);
         mx_split(2.0f * O.x, ohx, olx); mx_split(2.0f * O.y, ohy, oly); mx_split(2.0f * O.z, ohz, olz); mx_split(-k2, k2h, k2l);
         const _Float16 z = (_Float16)0.0f, m1 = (_Float16)-1.0f;
+        if (!active || !ok) {
+            /* the two special lanes are decided by their operands, not by masks in the tile loop: with Dn = O = 0 the test
+             * reads q = -k2 - w, and |w| <= 64^2 for a real record (60000 for a dummy).  No ray: -k2 = -60000, q < 0 for
+             * every record, never a candidate.  Origin out of range (or NaN): -k2 = +60000, q >= 0 for every record, all
+             * of them candidates (a dummy too: the exact test rejects it). */
+            dhx = dlx = dhy = dly = dhz = dlz = k1h = k1l = z;
+            ohx = olx = ohy = oly = ohz = olz = k2l = z;
+            k2h = active ? (_Float16)60000.0f : (_Float16)-60000.0f;
+        }
         const mirt_h8 glo = {dhx, dhx, dlx, dlx, dhy, dhy, dly, dly}, ghi = {dhz, dhz, dlz, dlz, k1h, k1l, z, z};
         const mirt_h8 elo = {ohx, ohx, olx, olx, ohy, ohy, oly, oly}, ehi = {ohz, ohz, olz, olz, k2h, k2l, m1, m1};
         /* X operand: lanes 0-31 their own low half, lanes 32-63 the high half of ray (lane - 32);
@@ -612,8 +618,8 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
             }
             /* lanes 0-31 hold (ray l, rows of sub 0) and (ray l + 32, sub 0); lanes 32-63 (ray l - 32, sub 1) and (ray l, sub 1) */
             auto sw = __builtin_amdgcn_permlane32_swap(mx, my, false, false);
-            mx = (sw[0] & amask) | omask; /* this lane's ray, spheres 32 t .. 32 t + 15 */
-            my = (sw[1] & amask) | omask; /*                  spheres 32 t + 16 .. 32 t + 31 */
+            mx = sw[0]; /* this lane's ray, spheres 32 t .. 32 t + 15 */
+            my = sw[1]; /*                  spheres 32 t + 16 .. 32 t + 31 */
 #ifdef MIRT_VERIFY_BROAD
             for (uint32_t k_ = 0; k_ < 32; ++k_) { /* exact discriminant >= 0 must imply the candidate bit */
                 const uint32_t i_ = t * 32 + k_;
