@@ -540,7 +540,7 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
     best.idx = 0xFFFFFFFFu;
     const R a_true = ray_a(ray.d);
     const uint32_t ntiles = (sc.n + 31) / 32;
-    uint32_t(*ent)[MIRT_WAVE] = L.ent[w];
+    uint2(*ent2)[MIRT_WAVE] = reinterpret_cast<uint2(*)[MIRT_WAVE]>(L.ent[w]); /* one entry per tile: both 16-sphere halves */
     /* ---- the ray's operands ---- */
     mirt_h8 bgx, bgy, bex, bey;
     {
@@ -637,11 +637,9 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
             }
 #endif
             /* unconditional writes, conditional advance (cnt <= LDS_ENT_CAP - 2 here: a nearly full list flushes below) */
-            ent[cnt][lane] = mx;
-            cnt += ((mx & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
-            ent[cnt][lane] = my;
-            cnt += ((my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
-            flush = __ballot(cnt > LDS::LDS_ENT_CAP - 2) != 0ull; /* no room for another tile */
+            ent2[cnt][lane] = make_uint2(mx, my);
+            cnt += ((mx & my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
+            flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull; /* no room for another tile */
         }
         pt.stamp(PH_BROAD);
         /* ---- narrow phase: as in trace_cons ---- */
@@ -649,20 +647,21 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
             uint32_t k = 0, m = 0, gi = 0;
             for (;;) {
                 if (m == 0 && k < cnt) {
-                    const uint32_t e = ent[k][lane];
+                    const uint2 e = ent2[k][lane];
                     ++k;
-                    m = ~e & 0xFFFFu;
-                    gi = (gbase + (e >> 16)) * MIRT_CGROUP + (MIRT_CGROUP - 1);
+                    m = (~e.x & 0xFFFFu) | (~e.y << 16); /* both halves of the tile: groups g and g + 1 */
+                    gi = (gbase + (e.x >> 16)) * MIRT_CGROUP + (MIRT_CGROUP - 1);
                 }
                 if (__ballot(m != 0) == 0ull) break;
                 if (m != 0) {
                     const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
                     m &= m - 1u;
+                    const uint32_t idx = gi - bit + (bit >= 16u ? 32u : 0u);
                     if constexpr (LDS::GEOM_LDS) {
-                        if (RES) narrow_test(sc, GeomLdsT<LDS>{L}, gi - bit, ray, a_true, tmin, best);
-                        else narrow_test(sc, GeomGlobal<R>{sc}, gi - bit, ray, a_true, tmin, best);
+                        if (RES) narrow_test(sc, GeomLdsT<LDS>{L}, idx, ray, a_true, tmin, best);
+                        else narrow_test(sc, GeomGlobal<R>{sc}, idx, ray, a_true, tmin, best);
                     } else {
-                        narrow_test(sc, GeomGlobal<R>{sc}, gi - bit, ray, a_true, tmin, best);
+                        narrow_test(sc, GeomGlobal<R>{sc}, idx, ray, a_true, tmin, best);
                     }
                     ++narrow_count;
                 }
