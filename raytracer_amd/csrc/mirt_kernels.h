@@ -476,7 +476,7 @@ struct MxLds {
     float4 A[MIRT_LDS_RECORDS];
     float4 B[MIRT_LDS_RECORDS];
     uint16_t mat[MIRT_LDS_RECORDS];
-    static constexpr uint32_t LDS_ENT_CAP = 12;
+    static constexpr uint32_t LDS_ENT_CAP = 12; /* in 4-byte words: trace_mx stores 6 tile entries of 8 bytes */
     uint32_t ent[MIRT_F32_WAVES][LDS_ENT_CAP][MIRT_WAVE];
     DevMaterial<float> mats[MIRT_MX_LDS_MATS]; /* the scene's materials when they fit: the shading of a segment starts with this record */
     /* all threads of the block; true when the scene is resident (larger scenes read their operands through L1/L2) */
@@ -636,7 +636,8 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
                 if (active && dd_ >= (R)0.0 && ((word_ >> (15 - (k_ & 15u))) & 1u)) atomicAdd(sc.dbg, 1ull);
             }
 #endif
-            /* unconditional writes, conditional advance (cnt <= LDS_ENT_CAP - 2 here: a nearly full list flushes below) */
+            /* one 8-byte entry per tile (the list holds LDS_ENT_CAP / 2 of them): unconditional write, conditional advance
+             * (cnt < LDS_ENT_CAP / 2 here: a full list flushes below) */
             ent2[cnt][lane] = make_uint2(mx, my);
             cnt += ((mx & my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
             flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull; /* no room for another tile */
