@@ -268,7 +268,7 @@ def main():
                 # HBM bytes per launch of this kernel, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE in separate passes
                 # (profiles/r01_mx_hbm_traffic.txt: 17-35 MiB fetched + 772 MiB written, the per-item partial sums; not re-measured by this script).  Only quoted for the workload it was taken on.
                 "traffic": 8.3e8 if (args.workload == "balls1080p" and (W, cam.pod.samples_per_pixel, world) == (1920, 64, 1) and kind in (0, 1)) else None,
-                "kernel": ["render_kernel_f32", "render_kernel_f32_mx", "render_kernel_f32_bvh(_lds)", "render_kernel_f64<2>", "render_kernel_f64_mx"][kind],
+                "kernel": ["render_kernel_f32_tiny" if scene.flat.n_spheres <= 8 else "render_kernel_f32", "render_kernel_f32_mx", "render_kernel_f32_bvh(_lds)", "render_kernel_f64<2>", "render_kernel_f64_mx"][kind],
                 "kernel_ms_avg": round(kern_ms / max(1, len(stats)), 3),
                 "flops_per_segment": round(flops / max(seg, 1), 1),
                 "note": "algorithmic flops = 18/static sphere test + 27/moving sphere test + 5/segment (SURVEY.md 8d); rank 0's launches; duration = HIP events around each launch on its own stream"

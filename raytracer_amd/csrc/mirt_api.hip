@@ -489,7 +489,7 @@ static void choose_chunks(uint64_t n_pixels, uint32_t nsamples, size_t real_byte
 
 /* the two render kernels behind one name */
 static const void* render_fn(double, int bvh) { return bvh == 3 ? (const void*)render_kernel_f64_mx : (const void*)render_kernel_f64<2>; }
-static const void* render_fn(float, int bvh) { return bvh == 3 ? (const void*)render_kernel_f32_mx : bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
+static const void* render_fn(float, int bvh) { return bvh == 4 ? (const void*)render_kernel_f32_tiny : bvh == 3 ? (const void*)render_kernel_f32_mx : bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
 static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam,
                                  const DevPart& part, const RenderParams& rp, double* partial, DevStats* stats) {
     if (bvh == 3) hipLaunchKernelGGL(render_kernel_f64_mx, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
@@ -497,7 +497,8 @@ static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStre
 }
 static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<float>& sc, const DevCamera<float>& cam,
                                  const DevPart& part, const RenderParams& rp, float* partial, DevStats* stats) {
-    if (bvh == 3) hipLaunchKernelGGL(render_kernel_f32_mx, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    if (bvh == 4) hipLaunchKernelGGL(render_kernel_f32_tiny, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    else if (bvh == 3) hipLaunchKernelGGL(render_kernel_f32_mx, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh == 2) hipLaunchKernelGGL(render_kernel_f32_bvh_lds, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh) hipLaunchKernelGGL(render_kernel_f32_bvh, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else hipLaunchKernelGGL(render_kernel_f32, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
@@ -508,8 +509,8 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
                          uint8_t* d_rgb8, hipStream_t st, bool use_bvh, bool mx, uint32_t first_sample = 0, uint32_t sample_count = 0xFFFFFFFFu,
                          void* d_accum = nullptr) {
     /* closest-hit front end: 0 = brute force, VALU broad phase; 1 = tree in HBM/L2; 2 = tree, records and spheres resident in
-     * LDS; 3 = brute force, broad phase on the matrix pipe */
-    const int bvh = mx ? 3 : !use_bvh ? 0
+     * LDS; 3 = brute force, broad phase on the matrix pipe; 4 = f32, a handful of spheres (render_kernel_f32_tiny) */
+    const int bvh = mx ? 3 : !use_bvh ? ((sizeof(R) == 4 && s->n <= MIRT_TINY_SCENE) ? 4 : 0) /* 4 = the f32 kernel for a handful of spheres */
                     : (s->bvh_n_nodes <= MIRT_BVH_LDS_NODES && s->bvh_n_recs <= MIRT_LDS_RECORDS && s->n <= MIRT_LDS_RECORDS &&
                        s->bvh_depth <= MIRT_BVH_LDS_STACK && s->n_materials <= 0x10000u && s->bvh_root != MIRT_BVH_NONE) ? 2 : 1;
     const uint32_t block = (sizeof(R) == 4 && bvh != 1) ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;

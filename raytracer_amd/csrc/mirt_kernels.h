@@ -479,6 +479,7 @@ struct MxLds {
     static constexpr uint32_t LDS_ENT_CAP = 12; /* in 4-byte words: trace_mx stores 6 tile entries of 8 bytes */
     uint32_t ent[MIRT_F32_WAVES][LDS_ENT_CAP][MIRT_WAVE];
     DevMaterial<float> mats[MIRT_MX_LDS_MATS]; /* the scene's materials when they fit: the shading of a segment starts with this record */
+    uint32_t params[120]; /* the block's copy of camera, partition and launch parameters (render_kernel_f32_mx) */
     /* all threads of the block; true when the scene is resident (larger scenes read their operands through L1/L2) */
     __device__ inline bool fill(const DevScene<float>& sc) {
         const bool res = sc.n <= MIRT_LDS_RECORDS && sc.n_materials <= 0x10000u;
@@ -1482,26 +1483,53 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
     }
 }
 
+/* Camera, partition and launch parameters are read once per loop iteration (item decode, ray generation) by code that sits
+ * between the register-hungry phases.  As kernel arguments they live in SGPRs for the whole launch and most of them end up
+ * spilled to VGPR lanes (62 SGPRs in render_kernel_f32_mx, one v_readlane per use: 275 of them in the kernel).  The render
+ * kernels copy them to LDS once per block and the loop reads that copy (bench frame 15.62 -> 15.20 ms). */
+template <class R> struct LaunchParams {
+    DevCamera<R> cam;
+    DevPart part;
+    RenderParams rp;
+};
+/* thread 0 writes; the caller's next block barrier publishes */
+template <class R>
+__device__ inline void stage_params(LaunchParams<R>* P, const DevCamera<R>& cam, const DevPart& part, const RenderParams& rp) {
+    if (threadIdx.x == 0) {
+        P->cam = cam;
+        P->part = part;
+        P->rp = rp;
+    }
+}
+
 template <int MIN_WAVES>
 __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel_f64(DevScene<double> sc, DevCamera<double> cam, DevPart part, RenderParams rp,
                                                                             double* __restrict__ partial, DevStats* __restrict__ stats) {
     __shared__ WaveLds<double> lds_all[MIRT_WAVES_PER_BLOCK];
+    __shared__ LaunchParams<double> P;
+    stage_params(&P, cam, part, rp);
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     TracerF64 tr{sc, lds_all[w]};
-    render_body(tr, sc, cam, part, rp, partial, stats, lane);
+    /* measured: the LDS copy pays where an iteration is short (a handful of spheres: textured 4K f64 17.98 -> 17.56 ms), not in
+     * the all-f64 loop over hundreds of spheres (115.3 -> 116.2 ms: the compiler keeps the copy in VGPRs there) */
+    if (sc.n <= MIRT_TINY_SCENE) render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane);
+    else render_body(tr, sc, cam, part, rp, partial, stats, lane);
 }
 /* parity mode with the broad phase on the matrix pipe: f32 filter, exact f64 narrow phase and shading */
 __global__ __launch_bounds__(MIRT_BLOCK, 3) void render_kernel_f64_mx(DevScene<double> sc, DevCamera<double> cam, DevPart part, RenderParams rp,
                                                                       double* __restrict__ partial, DevStats* __restrict__ stats) {
     __shared__ MxLds64 L;
-    const bool res = L.fill(sc);
+    __shared__ LaunchParams<double> P;
+    stage_params(&P, cam, part, rp);
+    const bool res = L.fill(sc); /* ends with the block barrier */
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     if (res) {
         TracerF64Mx<true> tr{sc, L, w};
-        render_body(tr, sc, cam, part, rp, partial, stats, lane);
+        render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane);
     } else {
         TracerF64Mx<false> tr{sc, L, w};
-        render_body(tr, sc, cam, part, rp, partial, stats, lane);
+        render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane);
     }
 }
 /* MIRT_FLAG_BVH: latency-bound per-lane traversal, small blocks, as many waves as the registers allow */
@@ -1510,16 +1538,20 @@ __global__ __launch_bounds__(MIRT_BLOCK) void render_kernel_f32_bvh(DevScene<flo
     __shared__ uint32_t stk[MIRT_WAVES_PER_BLOCK][MIRT_BVH_STACK][MIRT_WAVE];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     TracerF32Bvh<BvhGlobalStore, true> tr{sc, BvhGlobalStore{sc}, stk[w]};
+    /* no LDS copy of the parameters here (stage_params): it costs this kernel 42 VGPRs, i.e. two of its five waves per SIMD
+     * (stress 10 000: 58.1 -> 66.4 ms) */
     render_body(tr, sc, cam, part, rp, partial, stats, lane);
 }
 /* the same for scenes whose tree, records and spheres fit the LDS: one block of 16 waves per CU, no HBM in the loop */
 __global__ __launch_bounds__(MIRT_F32_BLOCK) void render_kernel_f32_bvh_lds(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
                                                                             float* __restrict__ partial, DevStats* __restrict__ stats) {
     __shared__ BvhLds L;
-    L.fill(sc);
+    __shared__ LaunchParams<float> P;
+    stage_params(&P, cam, part, rp);
+    L.fill(sc); /* ends with the block barrier */
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     TracerF32Bvh<BvhLdsStore, true> tr{sc, BvhLdsStore{L}, L.stk[w]};
-    render_body(tr, sc, cam, part, rp, partial, stats, lane);
+    render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane);
 }
 /* one block of 16 waves per CU: 4 waves per SIMD, <= 128 VGPRs */
 __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
@@ -1527,6 +1559,8 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
     __shared__ F32Lds L;
     const bool res = L.fill(sc);
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    /* no LDS copy of the parameters in this kernel (stage_params): 29.1 -> 29.5 ms on the bench frame, the copy ends up in
+     * VGPRs the tile loop wants; scenes of a few spheres, where it pays, have a kernel of their own below */
     if (res) {
         TracerF32<true> tr{sc, L, w};
         render_body(tr, sc, cam, part, rp, partial, stats, lane);
@@ -1535,19 +1569,35 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
         render_body(tr, sc, cam, part, rp, partial, stats, lane);
     }
 }
+/* scenes of <= MIRT_TINY_SCENE sorted slots (chosen by the host): TracerF32's exact-test-on-every-sphere path with short loop
+ * iterations, where reading the parameters from LDS instead of spilled SGPRs is worth 5 % (textured 4K 7.84 -> 7.41 ms) */
+__global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32_tiny(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
+                                                                         float* __restrict__ partial, DevStats* __restrict__ stats) {
+    __shared__ F32Lds L;
+    __shared__ LaunchParams<float> P;
+    stage_params(&P, cam, part, rp);
+    L.fill(sc); /* ends with the block barrier; a scene this small is always resident */
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    TracerF32<true> tr{sc, L, w};
+    render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane);
+}
 
 /* the same with the broad phase on the matrix pipe (scenes whose coordinates fit the split-f16 operands) */
 __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32_mx(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
                                                                        float* __restrict__ partial, DevStats* __restrict__ stats) {
     __shared__ MxLds L;
-    const bool res = L.fill(sc);
+    /* the LDS of this kernel is full: the parameter copy (stage_params) has its place inside MxLds */
+    static_assert(sizeof(LaunchParams<float>) <= sizeof(L.params), "MxLds::params too small");
+    LaunchParams<float>* P = reinterpret_cast<LaunchParams<float>*>(L.params);
+    stage_params(P, cam, part, rp);
+    const bool res = L.fill(sc); /* ends with the block barrier */
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     if (res) {
         TracerF32Mx<true> tr{sc, L, w};
-        render_body(tr, sc, cam, part, rp, partial, stats, lane);
+        render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
     } else {
         TracerF32Mx<false> tr{sc, L, w};
-        render_body(tr, sc, cam, part, rp, partial, stats, lane);
+        render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
     }
 }
 
