@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--accel", default="brute", choices=["brute", "valu", "bvh"],
                     help="closest-hit method: brute = the brute-force tile loop (the metric; broad phase on the matrix pipe where the scene allows it), "
                          "valu = the same loop with the broad phase kept on the vector ALU, bvh = the bounding-ball tree")
+    ap.add_argument("--chunk", type=int, default=0, help="mirt_opts.chunk_samples: lower bound of the samples per work item (0 = the library's choice)")
+    ap.add_argument("--group-chunks", type=int, default=0, help="mirt_opts.group_chunks (image-neutral tuning; 0 = automatic)")
+    ap.add_argument("--bvh-keep", type=int, default=0, help="mirt_opts.bvh_keep (image-neutral tuning of the tree traversal; 0 = automatic)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra launches (valu_broad, accel_bvh): profiling runs want one kernel")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames in flight (ring of scene handles and streams); 1 = one frame at a time; 0 = 1 on one GPU "
@@ -137,8 +140,9 @@ def main():
     real = torch.float32 if args.precision == 32 else torch.float64
     rows0 = dist.part_rows(H, S, 0, world)
     accel_flags = {"brute": 0, "valu": abi.FLAG_VALU_BROAD, "bvh": abi.FLAG_BVH}[args.accel]
+    cam.chunk_samples, cam.group_chunks = args.chunk, args.group_chunks
     opts = cam.opts(precision=args.precision, seed=args.seed, strip_rows=S, part_index=rank, part_count=world,
-                    flags=abi.FLAG_COMPACT_ROWS | abi.FLAG_DEFER_STATS | accel_flags)
+                    flags=abi.FLAG_COMPACT_ROWS | abi.FLAG_DEFER_STATS | accel_flags, bvh_keep=args.bvh_keep)
     kind = lib.mirt_closest_hit_kind(ds.handle, C.byref(cam.pod), C.byref(opts))  # 0 valu, 1 matrix pipe, 2 tree, 3 f64, 4 f64 with the matrix-pipe broad phase
     abi.check(min(kind, 0))
     stream = torch.cuda.current_stream().cuda_stream

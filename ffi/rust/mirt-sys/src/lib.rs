@@ -5,7 +5,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const MIRT_ABI_VERSION: u32 = 1;
+pub const MIRT_ABI_VERSION: u32 = 2;
 pub const MIRT_MISS_ID: u32 = 0xFFFF_FFFF;
 
 pub const MIRT_OK: c_int = 0;
@@ -108,7 +108,10 @@ pub struct mirt_opts {
     pub strip_rows: u32,
     pub part_index: u32,
     pub part_count: u32,
-    pub _pad: u32,
+    pub chunk_samples: u32, // lower bound of the samples per work item (0 = 1); the one tuning field that reaches the image
+    pub group_chunks: u32,  // image-neutral tuning (0 = automatic)
+    pub bvh_keep: u32,      // image-neutral tuning, MIRT_FLAG_BVH (0 = automatic)
+    pub _reserved: [u32; 2],
 }
 
 #[repr(C)]
@@ -137,7 +140,7 @@ const _: () = assert!(std::mem::size_of::<mirt_texture>() == 64);
 const _: () = assert!(std::mem::size_of::<mirt_material>() == 64);
 const _: () = assert!(std::mem::size_of::<mirt_sphere>() == 64);
 const _: () = assert!(std::mem::size_of::<mirt_camera>() == 192);
-const _: () = assert!(std::mem::size_of::<mirt_opts>() == 32);
+const _: () = assert!(std::mem::size_of::<mirt_opts>() == 48);
 const _: () = assert!(std::mem::size_of::<mirt_stats>() == 72);
 
 extern "C" {

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MIRT_ABI_VERSION 1u
+#define MIRT_ABI_VERSION 2u
 #define MIRT_MISS_ID 0xFFFFFFFFu /* hit-id of a ray that hits nothing (SURVEY.md §8c "Hit id definition") */
 
 typedef enum mirt_status {
@@ -132,9 +132,14 @@ typedef enum mirt_precision {
  * the same scene handle collects them later.  For callers that keep several frames in flight - one scene handle and
  * one stream per frame in flight, since a handle owns one work queue and one set of partial sums. */
 #define MIRT_FLAG_DEFER_STATS 8u
+/* Brute-force loop: take the matrix-pipe broad phase also for scenes below its size threshold (24 spheres), where the
+ * vector-ALU loop is faster.  A tuning / test switch; the image does not depend on it. */
+#define MIRT_FLAG_MX_SMALL 16u
 
 /* Which rows a call renders: rows are grouped in strips of `strip_rows`; strip s is owned when
- * s % part_count == part_index (interleaved strips).  part_count <= 1 = whole image. */
+ * s % part_count == part_index (interleaved strips).  part_count <= 1 = whole image.
+ * The image is a function of (scene, camera, precision, seed, chunk_samples) and of nothing else: no environment
+ * variable is read by any entry point.  Zero-initialise the struct; 0 always means "the library's default". */
 typedef struct mirt_opts {
     uint32_t precision;  /* mirt_precision */
     uint32_t flags;
@@ -142,7 +147,15 @@ typedef struct mirt_opts {
     uint32_t strip_rows; /* 0 -> 8 */
     uint32_t part_index;
     uint32_t part_count;
-    uint32_t _pad;
+    /* Lower bound for the samples per work item (0 -> 1; the library doubles it until the per-item sums of the whole
+     * frame fit their budget; mirt_pass_granularity returns the value in force).  A pixel's radiance is the sum, in
+     * chunk order, of per-item sums, so this is the one tuning field that reaches the last bits of the image: callers
+     * that resume a checkpoint (mirt_render_pass) must pass the value the checkpoint was written with. */
+    uint32_t chunk_samples;
+    uint32_t group_chunks; /* tuning, image-neutral: chunks of a pixel kept together in the queue order (0 -> automatic) */
+    uint32_t bvh_keep;     /* tuning, image-neutral, MIRT_FLAG_BVH: share (1..64, in 64ths) of the traversing lanes below
+                              which a wave suspends its tree queries (0 -> automatic) */
+    uint32_t _reserved[2]; /* must be 0 */
 } mirt_opts;
 
 /* Counters written by a render call (device-side exact counts). */
@@ -187,7 +200,12 @@ int mirt_render(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts
 /* Same as mirt_render / mirt_primary_hits but the outputs are DEVICE pointers on the scene's
  * device and the work is enqueued on `stream` (a hipStream_t, NULL = default stream).  The calls
  * synchronise the stream before returning only if `stats` is non-NULL.  Used by the multi-GPU
- * gather (the band is handed to RCCL without leaving HBM) and by bench.py. */
+ * gather (the band is handed to RCCL without leaving HBM) and by bench.py.
+ * A scene handle owns ONE work queue, ONE set of counters and ONE workspace of partial sums: render calls
+ * on the same handle are ordered one behind the other whatever their streams (each launch records an event,
+ * the next one's stream waits for it), so a second call on another stream is safe but does not overlap the
+ * first - keep one handle per frame in flight for that.  Host threads sharing a handle are serialised for
+ * the duration of the enqueue; distinct handles are independent. */
 int mirt_render_device(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
                        void* d_rgb_linear, uint8_t* d_rgb8, void* stream, mirt_stats* stats);
 int mirt_primary_hits_device(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,

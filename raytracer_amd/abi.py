@@ -13,6 +13,7 @@ FLAG_COMPACT_ROWS = 1
 FLAG_BVH = 2  # closest hit through the bounding-ball tree (f32 only); same image bit for bit
 FLAG_DEFER_STATS = 8  # _device render calls: return at once, mirt_render_wait() collects the statistics
 FLAG_VALU_BROAD = 4  # f32 brute force: broad phase on the vector ALU instead of the matrix pipe; same image bit for bit
+FLAG_MX_SMALL = 16  # matrix-pipe broad phase also for scenes below its size threshold (tests, tuning); same image bit for bit
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 
@@ -82,7 +83,10 @@ class MirtOpts(C.Structure):
         ("strip_rows", C.c_uint32),
         ("part_index", C.c_uint32),
         ("part_count", C.c_uint32),
-        ("_pad", C.c_uint32),
+        ("chunk_samples", C.c_uint32),  # lower bound of the samples per work item (0 = 1): the one tuning field that reaches the image's last bits
+        ("group_chunks", C.c_uint32),  # image-neutral tuning: chunks of a pixel kept together in the queue order (0 = automatic)
+        ("bvh_keep", C.c_uint32),  # image-neutral tuning, FLAG_BVH: suspension threshold in 64ths (0 = automatic)
+        ("_reserved", C.c_uint32 * 2),
     ]
 
 

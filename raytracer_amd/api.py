@@ -304,10 +304,13 @@ def f64_to_u32(value: float) -> Optional[int]:
     return int(value)  # truncation toward zero, like `as u32`
 
 
+DEFAULT_FLAGS = 0  # OR-ed into every mirt_opts.flags built here (tests set abi.FLAG_MX_SMALL)
+
+
 def _accel_flags(accel):
-    if accel not in (None, "brute", "bvh", "valu"):
+    if accel not in (None, "brute", "bvh", "valu", "matrix"):
         raise ValueError(f"unknown accel {accel!r}")
-    return abi.FLAG_BVH if accel == "bvh" else abi.FLAG_VALU_BROAD if accel == "valu" else 0
+    return abi.FLAG_BVH if accel == "bvh" else abi.FLAG_VALU_BROAD if accel == "valu" else abi.FLAG_MX_SMALL if accel == "matrix" else 0
 
 
 @dataclass
@@ -317,6 +320,8 @@ class Camera:
     precision: int = abi.F64
     device: int = 0
     last_stats: dict = field(default_factory=dict)
+    chunk_samples: int = 0  # mirt_opts.chunk_samples (0 = the library's choice)
+    group_chunks: int = 0  # mirt_opts.group_chunks (0 = automatic)
 
     @staticmethod
     def build(
@@ -386,10 +391,14 @@ class Camera:
     def height(self):
         return self.pod.img_height
 
-    def opts(self, precision=None, seed=None, strip_rows=0, part_index=0, part_count=1, flags=0) -> abi.MirtOpts:
+    def opts(self, precision=None, seed=None, strip_rows=0, part_index=0, part_count=1, flags=0, chunk_samples=None, group_chunks=None,
+             bvh_keep=0) -> abi.MirtOpts:
+        """mirt_opts for a call.  Tuning travels in the struct (the library reads no environment variable): this camera's
+        `chunk_samples` / `group_chunks` attributes and the module-wide DEFAULT_FLAGS fill what the caller leaves open."""
         return abi.MirtOpts(
-            self.precision if precision is None else precision, flags, self.seed if seed is None else seed,
-            strip_rows, part_index, part_count, 0,
+            self.precision if precision is None else precision, flags | DEFAULT_FLAGS, self.seed if seed is None else seed,
+            strip_rows, part_index, part_count, self.chunk_samples if chunk_samples is None else chunk_samples,
+            self.group_chunks if group_chunks is None else group_chunks, bvh_keep,
         )
 
     # -- the hot path: everything below runs in the HIP library -------------------------------------

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -57,15 +58,25 @@ struct mirt_scene {
     MxSet mx32, mx64;             /* balls around the f32 spheres (what the f32 kernels test) and around the f64 ones */
     mutable uint4* SM = nullptr;  /* operands and scale of the call being launched */
     mutable float mx_scale = 1.f;
-    DevStats* stats = nullptr; /* one per scene: calls on one scene handle are not re-entrant */
+    DevStats* stats = nullptr; /* one per scene: launches on one scene handle are ordered one after the other (ev_busy) */
     mutable std::vector<void*> allocs; /* everything freed with the scene (mutable: operand copies are made on first use) */
-    /* render workspace (per-item partial sums), grown on demand and kept until the scene is destroyed */
+    /* render workspace (per-item partial sums; f64: per-lane attenuation stacks), grown on demand and kept until the scene
+     * is destroyed */
     mutable void* partial = nullptr;
     mutable size_t partial_bytes = 0;
+    mutable void* att = nullptr;
+    mutable size_t att_bytes = 0;
+    /* A handle owns ONE work queue, ONE set of counters and ONE workspace.  Every render launch on the handle records
+     * ev_busy behind its kernels and the next launch - on whatever stream - waits for it first, so two calls on one handle
+     * never run side by side (callers that want frames in flight use one handle per frame in flight).  `lock` serialises
+     * host threads that share a handle for the duration of the enqueue. */
+    mutable hipEvent_t ev_busy = nullptr;
+    mutable bool launched = false;
+    mutable std::mutex lock;
     /* device frames behind the host-buffer entry points (mirt_render / mirt_render_pass), grown on demand like `partial` */
     mutable void* stage[3] = {nullptr, nullptr, nullptr};
     mutable size_t stage_bytes[3] = {0, 0, 0};
-    mutable hipEvent_t ev0 = nullptr, ev1 = nullptr; /* timing events of render calls that ask for statistics (created once) */
+    mutable hipEvent_t ev0 = nullptr, ev1 = nullptr; /* timing events of render calls that ask for statistics (created with the scene) */
     /* MIRT_FLAG_DEFER_STATS: the counters land in pinned host memory behind the launch, mirt_render_wait reads them */
     mutable hipEvent_t ev2 = nullptr;
     mutable DevStats* host_stats = nullptr;
@@ -417,6 +428,8 @@ static int make_part(const mirt_camera* cam, const mirt_opts* o, DevPart* p) {
 static int check_common(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o) {
     if (!s || !cam || !o) return fail(MIRT_ERR_INVALID, "null argument");
     if (o->precision != MIRT_F32 && o->precision != MIRT_F64) return fail(MIRT_ERR_INVALID, "mirt_opts.precision must be 32 or 64");
+    if (o->_reserved[0] || o->_reserved[1]) return fail(MIRT_ERR_INVALID, "mirt_opts._reserved must be 0 (zero-initialise the struct)");
+    if (o->bvh_keep > 64) return fail(MIRT_ERR_INVALID, "mirt_opts.bvh_keep is a share in 64ths (0 = automatic, 1..64)");
     if (cam->img_width == 0 || cam->img_height == 0) return fail(MIRT_ERR_INVALID, "empty image");
     if ((uint64_t)cam->img_width * cam->img_height > 0xFFFFFFFFull) return fail(MIRT_ERR_TOO_LARGE, "W*H must fit 32 bits (RNG pixel counter)");
     if (o->flags & MIRT_FLAG_BVH) {
@@ -426,17 +439,12 @@ static int check_common(const mirt_scene* s, const mirt_camera* cam, const mirt_
     return MIRT_OK;
 }
 /* Brute-force calls run their broad phase on the matrix pipe when the scene and the camera allow it (mx_pick); the f64
- * kernels use the balls built around the f64 spheres. */
+ * kernels use the balls built around the f64 spheres.  Decided by the arguments alone (no environment variable). */
 static const mirt_scene::MxSet& mx_set(const mirt_scene* s, const mirt_opts* o) { return o->precision == MIRT_F64 ? s->mx64 : s->mx32; }
 static bool use_mx(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, int* e) {
     if (o->flags & (MIRT_FLAG_BVH | MIRT_FLAG_VALU_BROAD)) return false;
-    bool forced = false;
-    if (const char* v = getenv("MIRT_BROAD")) { /* tuning knob: valu | matrix (matrix = also for scenes below the size threshold) */
-        if (!strcmp(v, "valu")) return false;
-        forced = !strcmp(v, "matrix");
-    }
     /* a handful of spheres is tested faster than the ray's operands are split and exchanged (3 spheres at 4K: 9.6 vs 10.1 ms) */
-    if (s->true_n < 24 && !forced) return false;
+    if (s->true_n < 24 && !(o->flags & MIRT_FLAG_MX_SMALL)) return false;
     return mx_pick(s, mx_set(s, o), cam, e);
 }
 static uint32_t grid_for(uint32_t W, uint32_t local_rows, uint32_t waves_per_block) {
@@ -476,27 +484,65 @@ static int launch_primary(const mirt_scene* s, const SceneBuffers<float>& b, con
  * n_pixels is the pixel count of the WHOLE frame, whatever part of it a call renders: a pixel's radiance is the sum, in
  * chunk order, of per-chunk sums, so its last bits depend on the chunk size - and the image must not depend on how many
  * GPUs share the frame (tests/test_gpu_parity.py::test_bench_frame_full_size_properties). */
-#define MIRT_PARTIAL_BUDGET (1024ull << 20)
-static void choose_chunks(uint64_t n_pixels, uint32_t nsamples, size_t real_bytes, uint32_t* chunk, uint32_t* chunks) {
-    uint64_t max_chunks = MIRT_PARTIAL_BUDGET / (std::max<uint64_t>(n_pixels, 1) * 3 * real_bytes);
+/* f64 (parity mode) gets the larger budget: there the aim is one sample per item wherever it fits, because only then is a
+ * pixel's sum the reference's sequential sum over its samples (camera.rs:242-246) bit for bit - 1080p x 64 spp needs 3.2 GB. */
+#define MIRT_PARTIAL_BUDGET_F32 (1024ull << 20)
+#define MIRT_PARTIAL_BUDGET_F64 (4096ull << 20)
+static void choose_chunks(uint64_t n_pixels, uint32_t nsamples, size_t real_bytes, uint32_t min_chunk, uint32_t* chunk, uint32_t* chunks) {
+    const uint64_t budget = real_bytes == 8 ? MIRT_PARTIAL_BUDGET_F64 : MIRT_PARTIAL_BUDGET_F32;
+    uint64_t max_chunks = budget / (std::max<uint64_t>(n_pixels, 1) * 3 * real_bytes);
     if (max_chunks < 1) max_chunks = 1;
-    uint32_t q = 1u;
-    if (const char* e = getenv("MIRT_CHUNK")) q = (uint32_t)std::max(1, atoi(e)); /* tuning knob */
-    while ((nsamples + q - 1) / q > max_chunks) q *= 2;
+    uint32_t q = min_chunk ? min_chunk : 1u; /* mirt_opts.chunk_samples */
+    while ((nsamples + q - 1) / q > max_chunks && q < 0x80000000u) q *= 2;
     *chunk = q;
     *chunks = (nsamples + q - 1) / q;
+}
+
+/* Device memory a render launch needs beyond its inputs and outputs: the counters and work-queue head, the per-item
+ * partial sums, and (f64) the per-lane attenuation stacks.  The scene handle's own workspace grows on demand with
+ * hipMalloc; the one behind mirt_render_device_static is a fixed slice of a file-scope device array and never grows. */
+struct Workspace {
+    DevStats* stats;
+    void** partial; size_t* partial_bytes;
+    void** att; size_t* att_bytes;
+    bool fixed;
+};
+static int ws_reserve(const Workspace& ws, void** buf, size_t* have, size_t need, const char* what) {
+    if (need <= *have) return MIRT_OK;
+    if (ws.fixed)
+        return fail(MIRT_ERR_TOO_LARGE, std::string("mirt_render_device_static: ") + what + " need " + std::to_string(need) + " bytes, the static scratch has " +
+                                            std::to_string(*have) + " for them ");
+    if (*buf) (void)hipFree(*buf); /* waits for the device: nothing in flight reads it any more */
+    *buf = nullptr;
+    *have = 0;
+    if (hipMalloc(buf, need) != hipSuccess) { *buf = nullptr; return fail(MIRT_ERR_NOMEM, std::string("hipMalloc failed (") + what + ", " + std::to_string(need) + " bytes)"); }
+    *have = need;
+    return MIRT_OK;
+}
+#define MIRT_ATT_STACK_LIMIT (8192ull << 20)
+
+/* resident blocks per CU of every render kernel, asked once per process (not per call) */
+static int occupancy_of(const void* fn, int block) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<const void*, int>, int>> cache;
+    std::lock_guard<std::mutex> g(mu);
+    for (const auto& c : cache) if (c.first.first == fn && c.first.second == block) return c.second;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    cache.push_back({{fn, block}, per_cu});
+    return per_cu;
 }
 
 /* the two render kernels behind one name */
 static const void* render_fn(double, int bvh) { return bvh == 3 ? (const void*)render_kernel_f64_mx : (const void*)render_kernel_f64<2>; }
 static const void* render_fn(float, int bvh) { return bvh == 4 ? (const void*)render_kernel_f32_tiny : bvh == 3 ? (const void*)render_kernel_f32_mx : bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
 static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam,
-                                 const DevPart& part, const RenderParams& rp, double* partial, DevStats* stats) {
-    if (bvh == 3) hipLaunchKernelGGL(render_kernel_f64_mx, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
-    else hipLaunchKernelGGL(render_kernel_f64<2>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+                                 const DevPart& part, const RenderParams& rp, double* partial, DevStats* stats, double* att) {
+    if (bvh == 3) hipLaunchKernelGGL(render_kernel_f64_mx, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats, att);
+    else hipLaunchKernelGGL(render_kernel_f64<2>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats, att);
 }
 static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<float>& sc, const DevCamera<float>& cam,
-                                 const DevPart& part, const RenderParams& rp, float* partial, DevStats* stats) {
+                                 const DevPart& part, const RenderParams& rp, float* partial, DevStats* stats, float*) {
     if (bvh == 4) hipLaunchKernelGGL(render_kernel_f32_tiny, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh == 3) hipLaunchKernelGGL(render_kernel_f32_mx, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh == 2) hipLaunchKernelGGL(render_kernel_f32_bvh_lds, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
@@ -505,8 +551,8 @@ static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStre
 }
 
 template <class R>
-static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mirt_camera* cam, const DevPart& part, uint64_t seed, void* d_lin,
-                         uint8_t* d_rgb8, hipStream_t st, bool use_bvh, bool mx, uint32_t first_sample = 0, uint32_t sample_count = 0xFFFFFFFFu,
+static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mirt_camera* cam, const mirt_opts* o, const DevPart& part, const Workspace& ws,
+                         void* d_lin, uint8_t* d_rgb8, hipStream_t st, bool use_bvh, bool mx, uint32_t first_sample = 0, uint32_t sample_count = 0xFFFFFFFFu,
                          void* d_accum = nullptr) {
     /* closest-hit front end: 0 = brute force, VALU broad phase; 1 = tree in HBM/L2; 2 = tree, records and spheres resident in
      * LDS; 3 = brute force, broad phase on the matrix pipe; 4 = f32, a handful of spheres (render_kernel_f32_tiny) */
@@ -516,9 +562,10 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     const uint32_t block = (sizeof(R) == 4 && bvh != 1) ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;
     uint64_t n_pixels = (uint64_t)cam->img_width * part.local_rows;
     if (n_pixels == 0) return MIRT_OK;
+    const uint64_t seed = o->seed;
     RenderParams rp;
     rp.nsamples = cam->samples_per_pixel ? cam->samples_per_pixel : 1u;
-    choose_chunks((uint64_t)cam->img_width * cam->img_height, rp.nsamples, sizeof(R), &rp.chunk, &rp.chunks);
+    choose_chunks((uint64_t)cam->img_width * cam->img_height, rp.nsamples, sizeof(R), o->chunk_samples, &rp.chunk, &rp.chunks);
     /* a progressive pass renders whole chunks [first / Q, (first + count) / Q) of the same decomposition the one-call render uses */
     rp.chunk_first = 0;
     rp.norm_samples = rp.nsamples;
@@ -536,11 +583,11 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     }
     /* queue order: passes of G = 2^g_shift chunks (render_body).  Long launches (>= 128 items per lane of the chip) keep all
      * chunks of a pixel together, short ones - an 8-GPU band of the bench frame has 63 - use passes of 4 (measured:
-     * profiles/r01_microbench.txt); MIRT_GROUP_CHUNKS is the tuning knob */
+     * profiles/r01_microbench.txt); mirt_opts.group_chunks is the tuning knob (image-neutral) */
     uint32_t G = n_pixels * rp.chunks >= 128ull * 1024ull * (uint64_t)s->n_cus ? 64u : 4u;
-    if (const char* e = getenv("MIRT_GROUP_CHUNKS")) G = (uint32_t)std::max(1, atoi(e));
+    if (o->group_chunks) G = o->group_chunks;
     rp.g_shift = 0;
-    while ((2u << rp.g_shift) <= G && (2u << rp.g_shift) <= rp.chunks) ++rp.g_shift;
+    while (rp.g_shift < 30 && (2u << rp.g_shift) <= G && (2u << rp.g_shift) <= rp.chunks) ++rp.g_shift;
     const uint64_t passes = (rp.chunks + (1u << rp.g_shift) - 1) >> rp.g_shift;
     if (n_pixels * (passes << rp.g_shift) > 0xFFFFFF00ull) return fail(MIRT_ERR_TOO_LARGE, "too many work items for one launch");
     rp.n_items = (uint32_t)(n_pixels * (passes << rp.g_shift)); /* queue slots; those beyond the last chunk are skipped */
@@ -554,38 +601,44 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     rp.d_W = make_fastdiv(cam->img_width);
     rp.d_strip = make_fastdiv(part.strip_rows);
     rp.keep_num = 0;
+    rp.att_lanes = 0;
+    int rc;
     size_t need = (size_t)rp.n_items * 3 * sizeof(R); /* one slot per queue position */
-    if (need > s->partial_bytes) {
-        if (s->partial) (void)hipFree(s->partial);
-        s->partial = nullptr;
-        s->partial_bytes = 0;
-        HIP_TRY(hipMalloc(&s->partial, need));
-        s->partial_bytes = need;
-    }
+    if ((rc = ws_reserve(ws, ws.partial, ws.partial_bytes, need, "the per-item partial sums"))) return rc;
     if (cam->max_bounce_depth == 0) {
         /* color(ray, 0) is black before any hit test (camera.rs:269-271): no segment is traced */
-        HIP_TRY(hipMemsetAsync(s->partial, 0, need, st));
+        HIP_TRY(hipMemsetAsync(*ws.partial, 0, need, st));
     } else {
         /* persistent grid: as many blocks as can be resident, every wave pulls items until the queue is empty */
-        int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_fn(R(), bvh), (int)block, 0));
-        if (per_cu < 1) per_cu = 1;
+        const int per_cu = occupancy_of(render_fn(R(), bvh), (int)block);
         uint64_t waves_needed = ((uint64_t)rp.n_items + 63) / 64;
         uint64_t grid = std::min<uint64_t>((uint64_t)s->n_cus * per_cu, (waves_needed + waves_per_block - 1) / waves_per_block);
         /* the last two full batches per wave are handed out one item per lane at a time */
         rp.tail_items = (uint32_t)std::min<uint64_t>(grid * waves_per_block * 2 * MIRT_QUEUE_BATCH, rp.n_items);
-        if (bvh == 1 || bvh == 2) { /* suspend a traversal once this share (in 64ths) of the traversing lanes is all that is left (tuning knob: MIRT_BVH_KEEP, 0..64) */
+        if (bvh == 1 || bvh == 2) { /* suspend a traversal once this share (in 64ths) of the traversing lanes is all that is left (mirt_opts.bvh_keep) */
             rp.keep_num = bvh == 1 ? 32 : 16; /* measured: profiles/r01_microbench.txt */
-            if (const char* e = getenv("MIRT_BVH_KEEP")) rp.keep_num = (uint32_t)std::min(64, std::max(0, atoi(e)));
+            if (o->bvh_keep) rp.keep_num = o->bvh_keep;
         }
-        launch_render_kernel((uint32_t)grid, block, bvh, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, rp, (R*)s->partial, s->stats);
+        R* att = nullptr;
+        if (sizeof(R) == 8) {
+            /* parity mode multiplies a path's attenuations back to front like the reference's recursion (camera.rs:277): each
+             * lane keeps the attenuations of the path in hand in a stack of its own, [bounce][rgb][lane of the grid] */
+            rp.att_lanes = (uint32_t)(grid * block);
+            const uint64_t att_need = (uint64_t)cam->max_bounce_depth * 3 * sizeof(R) * rp.att_lanes;
+            if (att_need > MIRT_ATT_STACK_LIMIT)
+                return fail(MIRT_ERR_TOO_LARGE, "f64 parity mode keeps one attenuation per bounce and lane: max_bounce_depth " + std::to_string(cam->max_bounce_depth) +
+                                                    " needs " + std::to_string(att_need) + " bytes (limit 8 GiB)");
+            if ((rc = ws_reserve(ws, ws.att, ws.att_bytes, (size_t)att_need, "the f64 attenuation stacks"))) return rc;
+            att = (R*)*ws.att;
+        }
+        launch_render_kernel((uint32_t)grid, block, bvh, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, rp, (R*)*ws.partial, ws.stats, att);
         HIP_TRY(hipGetLastError());
     }
     /* one wave per 64 pixels of a band row */
     const uint64_t rwaves = (uint64_t)part.local_rows * ((cam->img_width + 63u) / 64u);
     uint32_t rgrid = (uint32_t)((rwaves + MIRT_RESOLVE_WAVES - 1) / MIRT_RESOLVE_WAVES);
-    hipLaunchKernelGGL((resolve_kernel<R>), dim3(rgrid), dim3(MIRT_RESOLVE_WAVES * MIRT_WAVE), 0, st, (const R*)s->partial, dev_camera<R>(cam), part, rp, (uint32_t)n_pixels,
-                       (R*)d_lin, d_rgb8, s->stats, (R*)d_accum);
+    hipLaunchKernelGGL((resolve_kernel<R>), dim3(rgrid), dim3(MIRT_RESOLVE_WAVES * MIRT_WAVE), 0, st, (const R*)*ws.partial, dev_camera<R>(cam), part, rp, (uint32_t)n_pixels,
+                       (R*)d_lin, d_rgb8, ws.stats, (R*)d_accum);
     HIP_TRY(hipGetLastError());
     return MIRT_OK;
 }
@@ -649,7 +702,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
     if (d->n_spheres > 0xFFFFFF00u) { delete s; return fail(MIRT_ERR_TOO_LARGE, "too many spheres"); }
     /* statics first, each section in insertion order and padded to a whole broad-phase group */
     std::vector<uint32_t> order;
-    order.reserve((size_t)d->n_spheres + 2 * MIRT_GROUP);
+    order.reserve((size_t)d->n_spheres + MIRT_GROUP + 32);
     for (uint32_t i = 0; i < d->n_spheres; ++i)
         if (!d->spheres[i].moving) order.push_back(i);
     s->true_static = (uint32_t)order.size();
@@ -657,7 +710,10 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
     s->n_static = (uint32_t)order.size();
     for (uint32_t i = 0; i < d->n_spheres; ++i)
         if (d->spheres[i].moving) order.push_back(i);
-    while (order.size() % MIRT_GROUP) order.push_back(0xFFFFFFFFu);
+    /* ... and the whole array to whole 32-sphere tiles of the matrix-pipe broad phase (a multiple of the 16-record groups
+     * of trace_cons and of MIRT_GROUP): a lane whose operands say "every record of this tile is a candidate" (origin out of
+     * range, NaN) then meets a dummy record in every slot up to the end of the last tile, in HBM and in the LDS copies */
+    while (order.size() % 32u) order.push_back(0xFFFFFFFFu);
     s->n = (uint32_t)order.size();
     s->true_n = d->n_spheres;
     s->n_materials = d->n_materials;
@@ -735,6 +791,24 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
     std::vector<DevStats> st(1);
     memset(st.data(), 0, sizeof(DevStats));
     if ((rc = upload(s, st, &s->stats))) { mirt_scene_destroy(s); return rc; }
+    /* everything a render call needs besides its workspace is made here, at set-up: events, the pinned landing place of
+     * deferred statistics, this device's address of the static scratch array, the default operand set of the matrix-pipe
+     * broad phase - so that mirt_render_device_static never has to allocate */
+    {
+        hipError_t e = hipEventCreate(&s->ev0);
+        if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+        if (e == hipSuccess) e = hipEventCreate(&s->ev2);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_busy, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s->host_stats, sizeof(DevStats), hipHostMallocDefault);
+        if (e != hipSuccess) { mirt_scene_destroy(s); return fail(MIRT_ERR_HIP, std::string("scene set-up: ") + hipGetErrorString(e)); }
+        /* operands for a camera inside or near the scene (the scale then follows from the scene's extent alone) */
+        mirt_camera c0;
+        memset(&c0, 0, sizeof(c0));
+        for (const mirt_scene::MxSet* set : {&s->mx32, &s->mx64}) {
+            int e2 = 0;
+            if (s->true_n && mx_pick(s, *set, &c0, &e2) && (rc = mx_ensure(s, *set, e2))) { mirt_scene_destroy(s); return rc; }
+        }
+    }
     *out = s;
     return MIRT_OK;
 }
@@ -744,6 +818,8 @@ void mirt_scene_destroy(mirt_scene* s) {
     (void)hipSetDevice(s->device);
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->partial) (void)hipFree(s->partial);
+    if (s->att) (void)hipFree(s->att);
+    if (s->ev_busy) (void)hipEventDestroy(s->ev_busy);
     for (void* p : s->stage) if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -758,6 +834,7 @@ int mirt_primary_hits_device(const mirt_scene* s, const mirt_camera* cam, const 
     if (!d_id) return fail(MIRT_ERR_INVALID, "id output is required");
     DevPart part;
     if ((rc = make_part(cam, o, &part))) return rc;
+    std::lock_guard<std::mutex> guard(s->lock);
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     int mx_e = 0;
@@ -768,22 +845,22 @@ int mirt_primary_hits_device(const mirt_scene* s, const mirt_camera* cam, const 
 }
 
 static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t first_sample, uint32_t sample_count, void* d_accum,
-                       void* d_lin, uint8_t* d_rgb8, void* stream, mirt_stats* stats);
+                       void* d_lin, uint8_t* d_rgb8, void* stream, mirt_stats* stats, bool use_static);
 int mirt_render_device(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, void* d_lin, uint8_t* d_rgb8, void* stream,
                        mirt_stats* stats) {
-    return render_impl(s, cam, o, 0, 0xFFFFFFFFu, nullptr, d_lin, d_rgb8, stream, stats);
+    return render_impl(s, cam, o, 0, 0xFFFFFFFFu, nullptr, d_lin, d_rgb8, stream, stats, false);
 }
 int mirt_render_pass_device(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t first_sample, uint32_t sample_count,
                             void* d_accum, void* d_lin, uint8_t* d_rgb8, void* stream, mirt_stats* stats) {
     if (sample_count == 0xFFFFFFFFu) return fail(MIRT_ERR_INVALID, "pass: sample_count out of range");
-    return render_impl(s, cam, o, first_sample, sample_count, d_accum, d_lin, d_rgb8, stream, stats);
+    return render_impl(s, cam, o, first_sample, sample_count, d_accum, d_lin, d_rgb8, stream, stats, false);
 }
 uint32_t mirt_pass_granularity(const mirt_camera* cam, const mirt_opts* o) {
     if (!cam || !o || !cam->samples_per_pixel) return 0;
     DevPart part;
     if (make_part(cam, o, &part)) return 0;
     uint32_t chunk = 1, chunks = 1;
-    choose_chunks((uint64_t)cam->img_width * cam->img_height, cam->samples_per_pixel, o->precision == MIRT_F64 ? 8 : 4, &chunk, &chunks);
+    choose_chunks((uint64_t)cam->img_width * cam->img_height, cam->samples_per_pixel, o->precision == MIRT_F64 ? 8 : 4, o->chunk_samples, &chunk, &chunks);
     return chunk;
 }
 /* diagnostic builds (-DMIRT_VERIFY_BROAD, -DMIRT_PHASE_TIMING, ...): what the kernels counted, on stderr */
@@ -841,41 +918,59 @@ int mirt_render_wait(const mirt_scene* s, mirt_stats* stats) {
     print_diagnostics(*s->host_stats);
     return MIRT_OK;
 }
+/* mx operands of this call's scale: resident already, or (growing workspaces only) uploaded now */
+static int mx_ready(const mirt_scene* s, const mirt_scene::MxSet& set, int e, bool may_allocate) {
+    for (const auto& c : set.cache)
+        if (c.first == e) return mx_ensure(s, set, e);
+    if (!may_allocate)
+        return fail(MIRT_ERR_INVALID, "mirt_render_device_static: the matrix-pipe operands for this camera's distance are not resident yet - make one "
+                                      "mirt_render_device / mirt_primary_hits_device call with this camera at set-up, or pass MIRT_FLAG_VALU_BROAD");
+    return mx_ensure(s, set, e);
+}
 static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t first_sample, uint32_t sample_count, void* d_accum,
-                       void* d_lin, uint8_t* d_rgb8, void* stream, mirt_stats* stats) {
+                       void* d_lin, uint8_t* d_rgb8, void* stream, mirt_stats* stats, bool use_static) {
     int rc = check_common(s, cam, o);
     if (rc) return rc;
     DevPart part;
     if ((rc = make_part(cam, o, &part))) return rc;
+    std::lock_guard<std::mutex> guard(s->lock);
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool defer = (o->flags & MIRT_FLAG_DEFER_STATS) != 0;
     if (defer) stats = nullptr; /* they come from mirt_render_wait */
-    if ((stats || defer) && !s->ev0) {
-        HIP_TRY(hipEventCreate(&s->ev0));
-        HIP_TRY(hipEventCreate(&s->ev1));
-    }
-    if (defer && !s->ev2) {
-        HIP_TRY(hipEventCreate(&s->ev2));
-        HIP_TRY(hipHostMalloc((void**)&s->host_stats, sizeof(DevStats), hipHostMallocDefault));
-    }
     if (s->pending) return fail(MIRT_ERR_INVALID, "a deferred render on this scene handle has not been collected (mirt_render_wait)");
     int mx_e = 0;
     const bool mx = use_mx(s, cam, o, &mx_e);
-    if (mx && (rc = mx_ensure(s, mx_set(s, o), mx_e))) return rc; /* before the timed region: the first call at a new scale uploads operands */
-    HIP_TRY(hipMemsetAsync(s->stats, 0, sizeof(DevStats), st)); /* counters and the work-queue head */
+    if (mx && (rc = mx_ready(s, mx_set(s, o), mx_e, !use_static))) return rc; /* before the timed region: the first call at a new scale uploads operands */
+    /* where the launch keeps its counters, partial sums and attenuation stacks */
+    unsigned char* sp = nullptr;
+    void *sp_partial = nullptr, *sp_att = nullptr;
+    size_t sp_partial_bytes = 0, sp_att_bytes = 0;
+    Workspace ws{s->stats, &s->partial, &s->partial_bytes, &s->att, &s->att_bytes, false};
+    if (use_static) {
+        return fail(MIRT_ERR_INVALID, "no static workspace in this build");
+    } else if (s->launched) {
+        /* the previous launch on this handle - on whatever stream - owns the queue head, the counters and the workspace until
+         * it is done: order this one behind it */
+        HIP_TRY(hipStreamWaitEvent(st, s->ev_busy, 0));
+    }
+    HIP_TRY(hipMemsetAsync(ws.stats, 0, sizeof(DevStats), st)); /* counters and the work-queue head */
     if (stats || defer) {
         e0 = s->ev0;
         e1 = s->ev1;
         HIP_TRY(hipEventRecord(e0, st));
     }
     rc = o->precision == MIRT_F64
-             ? launch_render<double>(s, s->f64, cam, part, o->seed, d_lin, d_rgb8, st, false, mx, first_sample, sample_count, d_accum)
-             : launch_render<float>(s, s->f32, cam, part, o->seed, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0, mx, first_sample, sample_count, d_accum);
+             ? launch_render<double>(s, s->f64, cam, o, part, ws, d_lin, d_rgb8, st, false, mx, first_sample, sample_count, d_accum)
+             : launch_render<float>(s, s->f32, cam, o, part, ws, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0, mx, first_sample, sample_count, d_accum);
+    if (!use_static) {
+        /* also after a failed enqueue: whatever did get onto the stream still uses the handle's memory */
+        if (hipEventRecord(s->ev_busy, st) == hipSuccess) s->launched = true;
+    }
     if (defer && !rc) { /* nothing waits here: the counters follow the launch into pinned memory */
         HIP_TRY(hipEventRecord(e1, st));
-        HIP_TRY(hipMemcpyAsync(s->host_stats, s->stats, sizeof(DevStats), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(s->host_stats, ws.stats, sizeof(DevStats), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(s->ev2, st));
         s->pending = true;
         s->pending_flags = o->flags;
@@ -888,7 +983,7 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
             memset(&h, 0, sizeof(h));
             float ms = 0.f;
             if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-            if (e == hipSuccess) e = hipMemcpy(&h, s->stats, sizeof(h), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(&h, ws.stats, sizeof(h), hipMemcpyDeviceToHost);
             if (e != hipSuccess) rc = fail(MIRT_ERR_HIP, std::string("render: ") + hipGetErrorString(e));
             fill_stats(s, o->flags, h, ms, stats);
             print_diagnostics(h);
@@ -896,7 +991,6 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
     }
     return rc;
 }
-
 int mirt_primary_hits(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t* id, void* t) {
     int rc = check_common(s, cam, o);
     if (rc) return rc;

@@ -1292,13 +1292,24 @@ struct RenderParams {
     uint32_t n_pixels;   /* band pixels */
     uint32_t g_shift;    /* queue order: 2^g_shift consecutive chunks of a pixel sit next to each other (see render_body) */
     uint32_t keep_num;   /* resumable tree traversal: go on while >= keep_num/64 of the traversing lanes are still at it (0: run to the end) */
+    uint32_t att_lanes;  /* f64 kernels: lanes of the grid = stride of the per-lane attenuation stacks (0 in the f32 kernels) */
 };
 
+/* Order of the floating-point operations that build a pixel (camera.rs:242-246, 277):
+ *   f64 (parity mode): the reference's.  color() multiplies a path's attenuations innermost first, a0 (a1 (... (a_k sky))),
+ *     so the lane keeps the attenuations of the path in hand in `att_stack` ([bounce][rgb][lane of the grid], HBM) and folds
+ *     them back to front when the path reaches the sky; with one sample per work item (the host's choice wherever the sums
+ *     fit their budget) K2b then adds the samples of a pixel one after the other like the loop of camera.rs:242-245.
+ *   f32 (throughput mode, the f32 spec of DESIGN.md): the running product thr = ((a0 a1) a2) ..., radiance = thr sky, and a
+ *     pixel is the sum in chunk order of per-item sums; the oracle's f32 instantiation restates exactly this. */
 template <class T>
 __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, const DevCamera<typename T::Real>& cam, const DevPart& part,
-                                   const RenderParams& rp, typename T::Real* __restrict__ partial, DevStats* __restrict__ stats, uint32_t lane) {
+                                   const RenderParams& rp, typename T::Real* __restrict__ partial, DevStats* __restrict__ stats, uint32_t lane,
+                                   typename T::Real* __restrict__ att_stack = nullptr) {
     typedef typename T::Real R;
+    constexpr bool REF_ORDER = sizeof(R) == 8;
     const bool aa = cam.spp > 0;
+    const size_t att_lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 
     /* wave-uniform: the reserved range of the queue */
     uint32_t q_next = 0, q_end = 0;
@@ -1435,7 +1446,14 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 V3<R> att;
                 RayT<R> nxt;
                 if (scatter(sc, tr.material_record(best.idx), ray, hit, dr, att, nxt)) {
-                    thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
+                    if constexpr (REF_ORDER) {
+                        const size_t o = (size_t)(bounce - 1u) * 3u * rp.att_lanes + att_lane;
+                        att_stack[o] = att.x;
+                        att_stack[o + rp.att_lanes] = att.y;
+                        att_stack[o + 2u * (size_t)rp.att_lanes] = att.z;
+                    } else {
+                        thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
+                    }
                     ray = nxt;
                     --depth_left;
                     done = depth_left == 0; /* color(.., 0) = black */
@@ -1446,7 +1464,15 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 V3<R> ud = unit(ray.d);
                 R a = (R)0.5 * (ud.y + (R)1.0);
                 V3<R> sky = {(R)1.0 * ((R)1.0 - a) + (R)0.5 * a, (R)1.0 * ((R)1.0 - a) + (R)0.7 * a, (R)1.0 * ((R)1.0 - a) + (R)1.0 * a};
-                radiance = {thr.x * sky.x, thr.y * sky.y, thr.z * sky.z};
+                if constexpr (REF_ORDER) {
+                    radiance = sky;
+                    for (uint32_t b = bounce; b-- > 0u;) { /* att * color(scattered, depth - 1), innermost first (camera.rs:277) */
+                        const size_t o = (size_t)b * 3u * rp.att_lanes + att_lane;
+                        radiance = {att_stack[o] * radiance.x, att_stack[o + rp.att_lanes] * radiance.y, att_stack[o + 2u * (size_t)rp.att_lanes] * radiance.z};
+                    }
+                } else {
+                    radiance = {thr.x * sky.x, thr.y * sky.y, thr.z * sky.z};
+                }
                 done = true;
             }
             if (done) {
@@ -1504,7 +1530,7 @@ __device__ inline void stage_params(LaunchParams<R>* P, const DevCamera<R>& cam,
 
 template <int MIN_WAVES>
 __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel_f64(DevScene<double> sc, DevCamera<double> cam, DevPart part, RenderParams rp,
-                                                                            double* __restrict__ partial, DevStats* __restrict__ stats) {
+                                                                            double* __restrict__ partial, DevStats* __restrict__ stats, double* __restrict__ att) {
     __shared__ WaveLds<double> lds_all[MIRT_WAVES_PER_BLOCK];
     __shared__ LaunchParams<double> P;
     stage_params(&P, cam, part, rp);
@@ -1513,12 +1539,12 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel_f64(DevSc
     TracerF64 tr{sc, lds_all[w]};
     /* measured: the LDS copy pays where an iteration is short (a handful of spheres: textured 4K f64 17.98 -> 17.56 ms), not in
      * the all-f64 loop over hundreds of spheres (115.3 -> 116.2 ms: the compiler keeps the copy in VGPRs there) */
-    if (sc.n <= MIRT_TINY_SCENE) render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane);
-    else render_body(tr, sc, cam, part, rp, partial, stats, lane);
+    if (sc.n <= MIRT_TINY_SCENE) render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane, att);
+    else render_body(tr, sc, cam, part, rp, partial, stats, lane, att);
 }
 /* parity mode with the broad phase on the matrix pipe: f32 filter, exact f64 narrow phase and shading */
 __global__ __launch_bounds__(MIRT_BLOCK, 3) void render_kernel_f64_mx(DevScene<double> sc, DevCamera<double> cam, DevPart part, RenderParams rp,
-                                                                      double* __restrict__ partial, DevStats* __restrict__ stats) {
+                                                                      double* __restrict__ partial, DevStats* __restrict__ stats, double* __restrict__ att) {
     __shared__ MxLds64 L;
     __shared__ LaunchParams<double> P;
     stage_params(&P, cam, part, rp);
@@ -1526,10 +1552,10 @@ __global__ __launch_bounds__(MIRT_BLOCK, 3) void render_kernel_f64_mx(DevScene<d
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     if (res) {
         TracerF64Mx<true> tr{sc, L, w};
-        render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane);
+        render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane, att);
     } else {
         TracerF64Mx<false> tr{sc, L, w};
-        render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane);
+        render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane, att);
     }
 }
 /* MIRT_FLAG_BVH: latency-bound per-lane traversal, small blocks, as many waves as the registers allow */

@@ -3,7 +3,7 @@
  * (/root/reference/src/main.rs:29-134) does with one hard-coded scene and camera, for all five of its scenes.
  *
  *   mirt_cli render --scene mars|bouncing_balls|scene|scene2|blur_scene [--width 400] [--spp 100] [--depth 50]
- *                   [--seed 1] [--layout-seed 1] [--precision 64|32] [--accel brute|valu|bvh] [--textures DIR] [--out FILE] [--passes N] [--checkpoint FILE] [--stop-after N]
+ *                   [--seed 1] [--layout-seed 1] [--precision 64|32] [--accel brute|valu|bvh] [--textures DIR] [--out FILE] [--passes N] [--checkpoint FILE] [--stop-after N] [--chunk Q]
  *        PPM P3 on stdout (or FILE), like the reference.  --spp 0 = the no-anti-aliasing branch.
  *   mirt_cli decode IN.jpg OUT.ppm      the image loader alone (binary PPM out)
  */
@@ -21,7 +21,7 @@ using namespace raytracer;
 
 static int usage() {
     std::cerr << "usage: mirt_cli render --scene NAME [--width W] [--spp N] [--depth D] [--seed S] [--layout-seed S] [--precision 64|32]\n"
-                 "                       [--accel brute|valu|bvh] [--textures DIR] [--out FILE] [--passes N] [--checkpoint FILE] [--stop-after N]\n"
+                 "                       [--accel brute|valu|bvh] [--textures DIR] [--out FILE] [--passes N] [--checkpoint FILE] [--stop-after N] [--chunk Q]\n"
                  "       mirt_cli decode IN.jpg OUT.ppm\n";
     return 2;
 }
@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
         std::map<std::string, std::string> opt = {{"--scene", "mars"}, {"--width", "400"}, {"--spp", "100"}, {"--depth", "50"}, {"--seed", "1"},
                                                   {"--layout-seed", "1"}, {"--precision", "64"}, {"--accel", "brute"},
                                                   {"--textures", "./presets/textures"}, {"--out", ""},
-                                                  {"--passes", "1"}, {"--checkpoint", ""}, {"--stop-after", "0"}};
+                                                  {"--passes", "1"}, {"--checkpoint", ""}, {"--stop-after", "0"}, {"--chunk", "0"}};
         for (int i = 2; i < argc; i += 2) {
             if (i + 1 >= argc || !opt.count(argv[i])) return usage();
             opt[argv[i]] = argv[i + 1];
@@ -78,6 +78,7 @@ int main(int argc, char** argv) {
         cam.precision = opt["--precision"] == "32" ? MIRT_F32 : MIRT_F64;
         cam.use_bvh = opt["--accel"] == "bvh";
         cam.valu_broad = opt["--accel"] == "valu";
+        cam.chunk_samples = (uint32_t)std::max(0, std::atoi(opt["--chunk"].c_str())); /* mirt_opts.chunk_samples */
         const uint32_t passes = (uint32_t)std::max(1, std::atoi(opt["--passes"].c_str()));
         const uint32_t stop_after = (uint32_t)std::max(0, std::atoi(opt["--stop-after"].c_str()));
         if (passes > 1 || !opt["--checkpoint"].empty()) {
@@ -86,15 +87,18 @@ int main(int argc, char** argv) {
              * after N passes, e.g. to exercise resuming) */
             Camera::Progress pr;
             const std::string ck = opt["--checkpoint"];
-            const uint64_t job[8] = {0x4D495254434B5031ull /* "MIRTCKP1" */, cam.pod.img_width, cam.pod.img_height, cam.pod.samples_per_pixel,
-                                     cam.pod.max_bounce_depth, cam.seed, (uint64_t)cam.precision, (uint64_t)scene.len()};
+            /* the samples per work item are part of the job: a pixel's sum is built from per-item sums, so sums written with one
+             * item size cannot be continued with another (a checkpoint from a run with a different --chunk is refused) */
+            const uint64_t job[9] = {0x4D495254434B5032ull /* "MIRTCKP2" */, cam.pod.img_width, cam.pod.img_height, cam.pod.samples_per_pixel,
+                                     cam.pod.max_bounce_depth, cam.seed, (uint64_t)cam.precision, (uint64_t)scene.len(), (uint64_t)cam.pass_granularity()};
             if (!ck.empty()) {
                 std::ifstream in(ck, std::ios::binary);
                 if (in) {
-                    uint64_t head[9];
+                    uint64_t head[10];
                     in.read((char*)head, sizeof head);
-                    if (!in || std::memcmp(head, job, sizeof job) != 0) throw std::runtime_error("checkpoint " + ck + " belongs to another job");
-                    pr.done = (uint32_t)head[8];
+                    if (!in || std::memcmp(head, job, sizeof job) != 0)
+                        throw std::runtime_error("checkpoint " + ck + " belongs to another job (image, samples, seed, precision, scene or samples per work item differ)");
+                    pr.done = (uint32_t)head[9];
                     pr.accum.assign(std::istreambuf_iterator<char>(in), std::istreambuf_iterator<char>());
                     std::cerr << "resuming " << ck << " at sample " << pr.done << " of " << spp << "\n";
                 }

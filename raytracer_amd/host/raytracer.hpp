@@ -262,6 +262,7 @@ class Camera {
     mirt_precision precision = MIRT_F64;
     bool use_bvh = false;              /* MIRT_FLAG_BVH: bounding-volume tree instead of the brute-force loop (MIRT_F32 only) */
     bool valu_broad = false;           /* MIRT_FLAG_VALU_BROAD: keep the f32 brute-force broad phase on the vector ALU */
+    uint32_t chunk_samples = 0;        /* mirt_opts.chunk_samples: lower bound of the samples per work item (0 = the library's choice) */
     mirt_stats last_stats{};
 
     /* The ten positional Options of camera.rs:123-134 with the defaults of :135-149 and the arithmetic of :151-182. */
@@ -318,13 +319,26 @@ class Camera {
         return c;
     }
 
-    /* Camera::render without the text emission: quantised bytes, W*H*3. */
-    std::vector<uint8_t> render_rgb8(const Scene& scene) {
-        std::vector<uint8_t> px((size_t)pod.img_width * pod.img_height * 3);
+    /* the mirt_opts of this camera's calls; everything that can reach the image travels in here (no environment variable) */
+    mirt_opts opts() const {
         mirt_opts o{};
         o.precision = precision;
         o.seed = seed;
         o.flags = (use_bvh ? MIRT_FLAG_BVH : 0u) | (valu_broad ? MIRT_FLAG_VALU_BROAD : 0u);
+        o.chunk_samples = chunk_samples;
+        return o;
+    }
+    /* samples per work item of this camera's image (mirt_pass_granularity): pass boundaries are multiples of it, and a
+     * checkpoint is only valid for the value it was written with */
+    uint32_t pass_granularity() const {
+        mirt_opts o = opts();
+        return mirt_pass_granularity(&pod, &o);
+    }
+
+    /* Camera::render without the text emission: quantised bytes, W*H*3. */
+    std::vector<uint8_t> render_rgb8(const Scene& scene) {
+        std::vector<uint8_t> px((size_t)pod.img_width * pod.img_height * 3);
+        mirt_opts o = opts();
         check(mirt_render(scene.handle(), &pod, &o, nullptr, px.data(), &last_stats));
         return px;
     }
@@ -339,10 +353,7 @@ class Camera {
     };
     std::vector<uint8_t> render_more(const Scene& scene, Progress& pr, uint32_t count) {
         const size_t n = (size_t)pod.img_width * pod.img_height * 3, rsz = precision == MIRT_F64 ? 8 : 4;
-        mirt_opts o{};
-        o.precision = precision;
-        o.seed = seed;
-        o.flags = (use_bvh ? MIRT_FLAG_BVH : 0u) | (valu_broad ? MIRT_FLAG_VALU_BROAD : 0u);
+        mirt_opts o = opts();
         const uint32_t g = mirt_pass_granularity(&pod, &o), spp = pod.samples_per_pixel;
         if (g == 0) throw RenderError("progressive rendering needs anti-aliasing samples");
         if (pr.accum.size() != n * rsz) {

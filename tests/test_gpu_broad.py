@@ -16,8 +16,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _matrix_pipe_for_small_scenes_too(monkeypatch):
     """Scenes of fewer than 24 spheres default to the vector ALU (cheaper than preparing a ray's operands); the tests here
-    want the matrix pipe wherever the operands fit, so they set the library's tuning knob."""
-    monkeypatch.setenv("MIRT_BROAD", "matrix")
+    want the matrix pipe wherever the operands fit, so every mirt_opts they build carries MIRT_FLAG_MX_SMALL."""
+    from raytracer_amd import api
+
+    monkeypatch.setattr(api, "DEFAULT_FLAGS", abi.FLAG_MX_SMALL)
 
 
 def bits(a):
@@ -184,7 +186,9 @@ def test_render_is_bit_identical_on_both_broad_phases(name):
 
 
 def test_tiny_scenes_default_to_the_vector_alu(monkeypatch):
-    monkeypatch.delenv("MIRT_BROAD")
+    from raytracer_amd import api
+
+    monkeypatch.setattr(api, "DEFAULT_FLAGS", 0)
     assert presets.default_camera(64, 0, 5).closest_hit_kind(presets.mars_texture_scene(), precision=abi.F32) == "valu"
     assert presets.bouncing_balls_camera(64, 0, 5).closest_hit_kind(presets.bouncing_balls_scene(1), precision=abi.F32) == "matrix"
 

@@ -403,12 +403,12 @@ def test_progressive_pass_argument_errors(scenes):
         cam0.render_pass(sc, 0, 1, acc, seed=1)
 
 
-def test_progressive_passes_with_larger_work_items(scenes, monkeypatch):
-    """With several samples per work item (large images; here forced through the library's tuning knob) pass boundaries are
+def test_progressive_passes_with_larger_work_items(scenes):
+    """With several samples per work item (large images; here asked for through mirt_opts.chunk_samples) pass boundaries are
     multiples of that size, and the result is still the one-call image."""
-    monkeypatch.setenv("MIRT_CHUNK", "4")
     sc, cam = scenes["balls"], SCENES["balls"][1](64, 10)
     cam.precision = abi.F32
+    cam.chunk_samples = 4
     assert cam.pass_granularity() == 4
     ref, ref8 = cam.render_arrays(sc, seed=2)
     acc = np.zeros((cam.height, cam.width, 3), np.float32)

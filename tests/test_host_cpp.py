@@ -220,3 +220,9 @@ def test_cli_progressive_passes_and_checkpoint_resume(tmp_path, prec):
     assert out2.read_bytes() == one.stdout
     other = subprocess.run(base[:-4] + ["--seed", "4", "--textures", ASSETS, "--checkpoint", str(ck)], capture_output=True, timeout=120)
     assert other.returncode == 1 and b"another job" in other.stderr
+    # sums written with one work-item size cannot be continued with another: the size is part of the job
+    ck2 = tmp_path / "job2.ck"
+    r3 = subprocess.run(base + ["--passes", "2", "--checkpoint", str(ck2), "--stop-after", "1", "--out", str(out2)], capture_output=True, timeout=120)
+    assert r3.returncode == 0 and ck2.exists()
+    r4 = subprocess.run(base + ["--passes", "2", "--checkpoint", str(ck2), "--chunk", "2"], capture_output=True, timeout=120)
+    assert r4.returncode == 1 and b"another job" in r4.stderr

@@ -7,11 +7,11 @@ import sys
 import numpy as np
 
 from oracle import binding
-from raytracer_amd import abi
+from raytracer_amd import abi, api
 from raytracer_amd.api import Camera, Dielectric, Lambertian, Metal, Scene, Sphere
 
 binding.load()
-os.environ["MIRT_BROAD"] = "matrix"
+api.DEFAULT_FLAGS = abi.FLAG_MX_SMALL  # matrix pipe also below its size threshold
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 mats = [Lambertian.new((0.6, 0.6, 0.6), 1.0), Metal.new((0.9, 0.9, 0.9), None), Dielectric.new(1.5)]

@@ -18,16 +18,13 @@ scenes = {"balls": presets.bouncing_balls_scene(1), "mars": presets.mars_texture
 bad = 0
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
-    for k in ("MIRT_CHUNK", "MIRT_GROUP_CHUNKS"):
-        os.environ.pop(k, None)
-    if rng.random() < 0.5:
-        os.environ["MIRT_CHUNK"] = str(int(rng.choice([1, 2, 4, 8])))
-    if rng.random() < 0.5:
-        os.environ["MIRT_GROUP_CHUNKS"] = str(int(rng.choice([1, 2, 4, 16, 64])))
+    knob_q = int(rng.choice([1, 2, 4, 8])) if rng.random() < 0.5 else 0   # mirt_opts.chunk_samples
+    knob_g = int(rng.choice([1, 2, 4, 16, 64])) if rng.random() < 0.5 else 0  # mirt_opts.group_chunks
     name = "balls" if rng.random() < 0.8 else "mars"
     sc = scenes[name]
     W, spp, depth = int(rng.integers(1, int(os.environ.get("FUZZ_MAX_W", "260")))), int(rng.integers(1, int(os.environ.get("FUZZ_MAX_SPP", "40")))), int(rng.integers(1, 12))
     cam = (presets.bouncing_balls_camera if name == "balls" else presets.default_camera)(W, spp, depth)
+    cam.chunk_samples, cam.group_chunks = knob_q, knob_g
     H = cam.height
     prec = abi.F64 if rng.random() < 0.3 else abi.F32
     real, rsz = (torch.float64, 8) if prec == abi.F64 else (torch.float32, 4)
@@ -64,6 +61,6 @@ for case in range(n_cases):
     if not ok:
         bad += 1
         print(f"MISMATCH seed {seed}: lin {bool(torch.equal(frame, ref))} bytes {bool(torch.equal(frame8, ref8))} segments {seg} vs {seg_ref}", flush=True)
-    print(f"case {seed}: {name} {W}x{H}x{spp} depth {depth} f{prec} flags {flags} parts {n} strip {S} cuts {cuts} Q {g} env {os.environ.get('MIRT_CHUNK')}/{os.environ.get('MIRT_GROUP_CHUNKS')}", flush=True)
+    print(f"case {seed}: {name} {W}x{H}x{spp} depth {depth} f{prec} flags {flags} parts {n} strip {S} cuts {cuts} Q {g} knobs {knob_q}/{knob_g}", flush=True)
 print(f"cases {n_cases}  mismatching frames: {bad}")
 sys.exit(1 if bad else 0)

@@ -13,7 +13,7 @@ import sys
 import numpy as np
 
 from oracle import binding
-from raytracer_amd import abi
+from raytracer_amd import abi, api
 from raytracer_amd.api import Camera, CheckerTexture, Dielectric, ImageTexture, Lambertian, Metal, Scene, Sphere
 
 binding.load()
@@ -23,10 +23,7 @@ bad = 0
 worst = {abi.F64: 1.0, abi.F32: 1.0}
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
-    if rng.random() < 0.5:
-        os.environ["MIRT_BROAD"] = "matrix"  # also below the size threshold of the matrix-pipe broad phase
-    else:
-        os.environ.pop("MIRT_BROAD", None)
+    api.DEFAULT_FLAGS = abi.FLAG_MX_SMALL if rng.random() < 0.5 else 0  # matrix pipe also below its size threshold
     img = rng.integers(0, 256, (int(rng.integers(1, 24)), int(rng.integers(1, 48)), 3), dtype=np.uint8)
 
     def material():

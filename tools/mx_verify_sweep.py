@@ -6,10 +6,10 @@ import sys
 
 import numpy as np
 
-from raytracer_amd import abi
+from raytracer_amd import abi, api
 from raytracer_amd.api import Camera, Dielectric, Lambertian, Metal, Scene, Sphere
 
-os.environ["MIRT_BROAD"] = "matrix"
+api.DEFAULT_FLAGS = abi.FLAG_MX_SMALL  # matrix pipe also below its size threshold
 PREC = abi.F64 if os.environ.get("MIRT_SWEEP_PRECISION") == "64" else abi.F32  # the f64 kernels use the same filter on balls around the f64 spheres
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 mats = [Lambertian.new((0.6, 0.6, 0.6), 1.0), Metal.new((0.9, 0.9, 0.9), None), Metal.new((0.8, 0.8, 0.8), 0.2), Dielectric.new(1.5)]

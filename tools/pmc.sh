@@ -2,7 +2,8 @@
 # PMC passes for bench.py (one rocprofv3 run per counter set; see MI355X guide: max 8 SQ counters per pass).
 # usage: tools/pmc.sh <tag> [bench args...]
 tag=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+root=${GRAFT_REPO_ROOT:-$PWD}
+cd /tmp && export TMPDIR=/tmp && cd $root
 run() { n=$1; shift; timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_$n -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras $BARGS > gpurun_out/pmc_${tag}_$n.log 2>&1 || exit 1; }
 BARGS="$*"
 run a SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU
