@@ -33,6 +33,7 @@ def load():
                                         C.c_int, u32, P(abi.MirtCamera)]
     lib.oracle_primary_hits.argtypes = [P(abi.MirtSceneDesc), P(abi.MirtCamera), u32, vp, u32, vp, vp]
     lib.oracle_render.argtypes = [P(abi.MirtSceneDesc), P(abi.MirtCamera), u32, u64, vp, u32, C.c_int, u32, u32, vp, vp, P(u64)]
+    lib.oracle_render_spec.argtypes = [P(abi.MirtSceneDesc), P(abi.MirtCamera), u32, u64, vp, u32, C.c_int, u32, u32, u32, vp, vp, P(u64)]
     lib.oracle_quantize.argtypes = [vp, u32, C.c_size_t, vp]
     lib.oracle_sphere_hit.argtypes = [P(abi.MirtSphere), P(dbl), P(dbl), dbl, dbl, dbl, P(dbl)]
     lib.oracle_aabb_slab.argtypes = [P(dbl), P(dbl), P(dbl), P(dbl), C.c_int, dbl, dbl]
@@ -74,16 +75,22 @@ def primary_hits(flat, cam_pod, precision=abi.F64, use_bvh=False):
     return ids, t
 
 
-def render(flat, cam_pod, precision=abi.F64, seed=0, use_bvh=False, threads=1, rows=None, want_rgb8=True):
+def render(flat, cam_pod, precision=abi.F64, seed=0, use_bvh=False, threads=1, rows=None, want_rgb8=True, spec_chunk=0):
+    """spec_chunk = 0: the reference's pixel arithmetic (recursion-order product, sequential sample sum).
+    spec_chunk = Q >= 1: the throughput kernels' (running product; sums of Q samples added in chunk order) - pass
+    mirt_pass_granularity's value (1 when anti-aliasing is off)."""
     H, W = cam_pod.img_height, cam_pod.img_width
     lin = np.zeros((H, W, 3), _real(precision))
     rgb8 = np.zeros((H, W, 3), np.uint8) if want_rgb8 else None
     seg = C.c_uint64(0)
     objs = flat.objects if use_bvh else None
     r0, r1 = (0, 0) if rows is None else rows
-    nan = load().oracle_render(C.byref(flat.desc), C.byref(cam_pod), precision, seed,
-                               None if objs is None else objs.ctypes.data, 0 if objs is None else len(objs),
-                               threads, r0, r1, lin.ctypes.data, None if rgb8 is None else rgb8.ctypes.data, C.byref(seg))
+    common = (C.byref(flat.desc), C.byref(cam_pod), precision, seed, None if objs is None else objs.ctypes.data, 0 if objs is None else len(objs), threads, r0, r1)
+    outs = (lin.ctypes.data, None if rgb8 is None else rgb8.ctypes.data, C.byref(seg))
+    if spec_chunk:
+        nan = load().oracle_render_spec(*common, spec_chunk, *outs)
+    else:
+        nan = load().oracle_render(*common, *outs)
     return lin, rgb8, int(seg.value), nan
 
 

@@ -551,6 +551,33 @@ static V3<R> color(const Scene<R>& sc, const Ray<R>& ray, uint32_t depth, Draws<
     return {(R)1.0 * ((R)1.0 - a) + (R)0.5 * a, (R)1.0 * ((R)1.0 - a) + (R)0.7 * a, (R)1.0 * ((R)1.0 - a) + (R)1.0 * a};
 }
 
+/* The f32 SPEC's pixel arithmetic (DESIGN.md "Two precisions"; no reference counterpart - the reference is f64 only and is
+ * restated by color() above).  The throughput kernels carry the running product thr = ((a0 a1) a2) ... of a path's
+ * attenuations and multiply the sky colour last, instead of the recursion's a0 (a1 (... sky)); same factors, another
+ * association, so the last bits differ.  The f32 instantiation of this oracle can restate THAT order, which lets the
+ * tests demand bit-equal f32 radiance from the HIP kernels; the f64 parity mode is held to color()'s order instead. */
+template <class R>
+static V3<R> color_running_product(const Scene<R>& sc, Ray<R> ray, uint32_t depth, Draws<R> dr, bool use_bvh) {
+    V3<R> thr{(R)1.0, (R)1.0, (R)1.0};
+    for (;;) {
+        if (depth == 0) return {(R)0.0, (R)0.0, (R)0.0};
+        HitRec<R> rec;
+        ++tl_segments;
+        if (!sc.hit(ray, Interval<R>{(R)0.001, std::numeric_limits<R>::infinity()}, rec, use_bvh)) break;
+        V3<R> att{(R)0.0, (R)0.0, (R)0.0};
+        Ray<R> sca{};
+        dr.bounce += 1;
+        if (!scatter(sc, sc.mats[sc.spheres[rec.id].mat], ray, rec, dr, att, sca)) return {(R)0.0, (R)0.0, (R)0.0};
+        thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
+        ray = sca;
+        --depth;
+    }
+    V3<R> ud = unit(ray.d);
+    R a = (R)0.5 * (ud.y + (R)1.0);
+    V3<R> sky = {(R)1.0 * ((R)1.0 - a) + (R)0.5 * a, (R)1.0 * ((R)1.0 - a) + (R)0.7 * a, (R)1.0 * ((R)1.0 - a) + (R)1.0 * a};
+    return {thr.x * sky.x, thr.y * sky.y, thr.z * sky.z};
+}
+
 /* camera.rs:209-230 with the RNG contract: bounce 0, dims 0,1 -> AA (w,h), dims 2,3 -> disk (r,theta), dim 4 -> time. */
 template <class R> static inline Ray<R> ray_for(const Cam<R>& c, uint32_t wn, uint32_t hn, const Draws<R>& dr) {
     R ua = dr.dim(0), ub = dr.dim(1);
@@ -583,16 +610,31 @@ template <class R> static inline bool quantize(R x, uint8_t& out) {
     return true;
 }
 
+/* spec_chunk == 0: the reference's pixel arithmetic (camera.rs:241-246, recursion order of camera.rs:277).
+ * spec_chunk == Q > 0: the throughput kernels' - running product per path, and the pixel as the sum, in chunk order, of the
+ * sums of Q consecutive samples (a work item of the HIP kernel; Q = mirt_pass_granularity). */
 template <class R>
 static int render_rows(const Scene<R>& sc, const Cam<R>& cam, uint64_t seed, bool use_bvh, uint32_t row0, uint32_t row1, R* lin,
-                       uint8_t* rgb8) {
+                       uint8_t* rgb8, uint32_t spec_chunk = 0) {
     int nan = 0;
     const uint64_t seg0 = tl_segments;
     for (uint32_t hn = row0; hn < row1; ++hn)
         for (uint32_t wn = 0; wn < cam.W; ++wn) {
             V3<R> px{(R)0.0, (R)0.0, (R)0.0};
             uint32_t pix = hn * cam.W + wn;
-            if (cam.spp > 0) { /* camera.rs:241-246 */
+            if (spec_chunk > 0) {
+                const uint32_t ns = cam.spp > 0 ? cam.spp : 1u;
+                for (uint32_t s0 = 0; s0 < ns; s0 += spec_chunk) {
+                    V3<R> item{(R)0.0, (R)0.0, (R)0.0};
+                    for (uint32_t s = s0; s < s0 + spec_chunk && s < ns; ++s) {
+                        Draws<R> dr{pix, s, 0, seed};
+                        Ray<R> r = cam.spp > 0 ? ray_for(cam, wn, hn, dr) : primary_ray(cam, wn, hn);
+                        item = item + color_running_product(sc, r, cam.depth, dr, use_bvh);
+                    }
+                    px = px + item;
+                }
+                if (cam.spp > 0) px = px * ((R)1.0 / (R)cam.spp);
+            } else if (cam.spp > 0) { /* camera.rs:241-246 */
                 for (uint32_t s = 0; s < cam.spp; ++s) {
                     Draws<R> dr{pix, s, 0, seed};
                     Ray<R> r = ray_for(cam, wn, hn, dr);
@@ -617,7 +659,7 @@ static int render_rows(const Scene<R>& sc, const Cam<R>& cam, uint64_t seed, boo
 
 template <class R>
 static int render_t(const mirt_scene_desc* d, const mirt_camera* c, uint64_t seed, const uint32_t* objects, uint32_t n_objects,
-                    int threads, uint32_t row_begin, uint32_t row_end, void* lin_v, uint8_t* rgb8, uint64_t* segments) {
+                    int threads, uint32_t row_begin, uint32_t row_end, void* lin_v, uint8_t* rgb8, uint64_t* segments, uint32_t spec_chunk = 0) {
     Scene<R> sc;
     sc.load(d);
     bool use_bvh = objects != nullptr && n_objects > 0;
@@ -627,7 +669,7 @@ static int render_t(const mirt_scene_desc* d, const mirt_camera* c, uint64_t see
     R* lin = (R*)lin_v;
     std::atomic<int> nan{0};
     if (threads <= 1) {
-        nan = render_rows(sc, cam, seed, use_bvh, row_begin, row_end, lin, rgb8);
+        nan = render_rows(sc, cam, seed, use_bvh, row_begin, row_end, lin, rgb8, spec_chunk);
     } else {
         std::atomic<uint32_t> next{row_begin};
         std::vector<std::thread> pool;
@@ -636,7 +678,7 @@ static int render_t(const mirt_scene_desc* d, const mirt_camera* c, uint64_t see
                 for (;;) {
                     uint32_t r = next.fetch_add(1);
                     if (r >= row_end) break;
-                    nan += render_rows(sc, cam, seed, use_bvh, r, r + 1, lin, rgb8);
+                    nan += render_rows(sc, cam, seed, use_bvh, r, r + 1, lin, rgb8, spec_chunk);
                 }
             });
         for (auto& t : pool) t.join();
@@ -740,6 +782,16 @@ int oracle_render(const mirt_scene_desc* d, const mirt_camera* c, uint32_t preci
                   uint64_t* segments) {
     if (precision == 64) return orc::render_t<double>(d, c, seed, objects, n_objects, threads, row_begin, row_end, rgb_linear, rgb8, segments);
     return orc::render_t<float>(d, c, seed, objects, n_objects, threads, row_begin, row_end, rgb_linear, rgb8, segments);
+}
+
+/* The same with the throughput kernels' pixel arithmetic (render_rows, spec_chunk = Q >= 1): what the f32 HIP kernels must
+ * reproduce bit for bit on scenes whose paths meet no transcendental function. */
+int oracle_render_spec(const mirt_scene_desc* d, const mirt_camera* c, uint32_t precision, uint64_t seed, const uint32_t* objects,
+                       uint32_t n_objects, int threads, uint32_t row_begin, uint32_t row_end, uint32_t chunk, void* rgb_linear, uint8_t* rgb8,
+                       uint64_t* segments) {
+    if (chunk == 0) chunk = 1;
+    if (precision == 64) return orc::render_t<double>(d, c, seed, objects, n_objects, threads, row_begin, row_end, rgb_linear, rgb8, segments, chunk);
+    return orc::render_t<float>(d, c, seed, objects, n_objects, threads, row_begin, row_end, rgb_linear, rgb8, segments, chunk);
 }
 
 int oracle_quantize(const void* lin, uint32_t precision, size_t n, uint8_t* out) {

@@ -1,0 +1,195 @@
+"""Bit-exact RADIANCE parity (not only hit ids): HIP path through the C ABI against the CPU oracle.  Needs a GPU.
+
+Where no transcendental function is on a path (no image texture: acos/atan2 of sphere.rs:72-76; no lens: sin/cos of
+point3.rs:106-110) every operation of the hot path is an IEEE + - * / sqrt (or an explicit fma mirrored in the oracle),
+so equal operation ORDER must give equal bits:
+  * MIRT_F64 (parity mode) against the oracle's restatement of the reference's own order - the recursion's
+    a0 (a1 (... sky)) of camera.rs:277 and the sequential sample sum of camera.rs:242-246;
+  * MIRT_F32 (throughput mode, the bench kernels) against the oracle's f32 instantiation of the f32 spec - running
+    product per path, per-work-item sums added in chunk order (oracle.cpp::color_running_product / render_rows).
+Scenes with image textures or a lens are held to "almost every channel bit-equal": OCML and glibc differ in the last ulp
+of acos/atan2/sin/cos, which moves a texel choice or a ray origin now and then.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, presets
+from raytracer_amd.api import Camera, ImageTexture, Lambertian, Scene
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+def balls_without_image(seed=1):
+    """bouncing_balls_scene with the one image-textured sphere given a plain colour: moving spheres, checker ground, fuzzy
+    and plain metal, glass - every material and texture kind except ImageTexture."""
+    src = presets.bouncing_balls_scene(seed)
+    plain = Lambertian.new((0.7, 0.4, 0.3), 0.9)
+    sc = Scene()
+    for o in src.objects:
+        if isinstance(getattr(o.mat, "texture", None), ImageTexture):
+            o.mat = plain
+        sc.add(o)
+    sc.build_bvh()
+    return sc
+
+
+def lensless_camera(w, spp, depth=50):
+    return Camera.build((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), w, 16.0 / 9.0, spp, math.radians(25.0), 10.0, 0.0, depth)
+
+
+@pytest.fixture(scope="module")
+def plain_balls():
+    return balls_without_image(1)
+
+
+@pytest.mark.parametrize("accel", [None, "valu"])
+def test_f64_radiance_bit_exact_in_the_reference_order(oracle, plain_balls, accel):
+    """f64 linear radiance == the oracle's, every bit of every channel: attenuations multiplied innermost first, samples
+    added one after the other (one sample per work item), both closest-hit front ends."""
+    sc, cam = plain_balls, lensless_camera(160, 16)
+    assert cam.pass_granularity(precision=abi.F64) == 1
+    lin, rgb8 = cam.render_arrays(sc, precision=abi.F64, seed=11, accel=accel)
+    o_lin, o_rgb8, o_seg, nan = oracle.render(sc.flat, cam.pod, abi.F64, seed=11, use_bvh=True, threads=8)
+    assert nan == 0 and cam.last_stats["segments"] == o_seg
+    assert np.array_equal(bits(lin), bits(o_lin))
+    assert np.array_equal(rgb8, o_rgb8)
+
+
+@pytest.mark.parametrize("depth", [1, 2, 7])
+def test_f64_radiance_bit_exact_depth_limits_and_no_aa(oracle, plain_balls, depth):
+    sc = plain_balls
+    for spp in (0, 5):
+        cam = lensless_camera(96, spp, depth)
+        lin, _ = cam.render_arrays(sc, precision=abi.F64, seed=3)
+        o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F64, seed=3, use_bvh=True, threads=8)
+        assert cam.last_stats["segments"] == o_seg
+        assert np.array_equal(bits(lin), bits(o_lin))
+
+
+@pytest.mark.parametrize("accel", [None, "valu", "bvh"])
+def test_f32_radiance_bit_exact_against_the_f32_spec(oracle, plain_balls, accel):
+    """The bench kernels (matrix-pipe broad phase, vector-ALU broad phase, tree) against the oracle's f32 instantiation in the
+    f32 spec's order.  10 spp with 4 samples per work item: a pixel is the sum of the sums of samples 0-3, 4-7, 8-9."""
+    sc = plain_balls
+    for spp, q in ((16, 0), (10, 4)):
+        cam = lensless_camera(160, spp)
+        cam.chunk_samples = q
+        g = cam.pass_granularity(precision=abi.F32)
+        assert g == max(q, 1)
+        lin, rgb8 = cam.render_arrays(sc, precision=abi.F32, seed=11, accel=accel)
+        o_lin, o_rgb8, o_seg, nan = oracle.render(sc.flat, cam.pod, abi.F32, seed=11, threads=8, spec_chunk=g)
+        assert nan == 0 and cam.last_stats["segments"] == o_seg
+        assert np.array_equal(bits(lin), bits(o_lin))
+        assert np.array_equal(rgb8, o_rgb8)
+
+
+@pytest.mark.parametrize("prec", [abi.F64, abi.F32])
+def test_stress_scene_radiance_bit_exact(oracle, prec):
+    """2 000 static spheres of all three materials (the C5 generator; no texture, no lens), streaming-tile kernels."""
+    sc, cam = presets.stress_scene(2000, 1), presets.stress_camera(128, 4, 50)
+    lin, _ = cam.render_arrays(sc, precision=prec, seed=5)
+    if prec == abi.F64:
+        o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F64, seed=5, use_bvh=True, threads=8)
+    else:
+        o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F32, seed=5, threads=8, spec_chunk=cam.pass_granularity(precision=abi.F32))
+    assert cam.last_stats["segments"] == o_seg
+    assert np.array_equal(bits(lin), bits(o_lin))
+
+
+@pytest.mark.parametrize("prec", [abi.F64, abi.F32])
+def test_textured_lens_scenes_are_bit_equal_almost_everywhere(oracle, prec):
+    """With the image texture and the lens back in (the bench scene and camera), what is left between the two sides is the
+    last ulp of acos/atan2/sin/cos: the lens makes every ray origin depend on sin/cos, so bit-equality holds only where
+    OCML and glibc agree - the order of the arithmetic no longer contributes.  Bars: >= 90 % of the channels bit-equal,
+    all within 1e-12 (f64) / 2e-5 (f32) relative except single samples that branch differently."""
+    sc, cam = presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(160, 8, 50)
+    lin, _ = cam.render_arrays(sc, precision=prec, seed=2)
+    if prec == abi.F64:
+        o_lin, _, _, _ = oracle.render(sc.flat, cam.pod, abi.F64, seed=2, use_bvh=True, threads=8)
+        tol = 1e-12
+    else:
+        o_lin, _, _, _ = oracle.render(sc.flat, cam.pod, abi.F32, seed=2, threads=8, spec_chunk=cam.pass_granularity(precision=abi.F32))
+        tol = 2e-5
+    same = float((bits(lin) == bits(o_lin)).mean())
+    close = float((np.abs(lin - o_lin) <= tol * (1 + np.abs(o_lin))).mean())
+    print(f"precision {prec}: bit-equal channels {same:.4f}, within tolerance {close:.4f}")
+    assert close >= 0.995
+    # without the lens only the textured sphere's uv is left
+    cam2 = lensless_camera(160, 8)
+    lin2, _ = cam2.render_arrays(sc, precision=prec, seed=2)
+    if prec == abi.F64:
+        o2, _, _, _ = oracle.render(sc.flat, cam2.pod, abi.F64, seed=2, use_bvh=True, threads=8)
+    else:
+        o2, _, _, _ = oracle.render(sc.flat, cam2.pod, abi.F32, seed=2, threads=8, spec_chunk=cam2.pass_granularity(precision=abi.F32))
+    same2 = float((bits(lin2) == bits(o2)).mean())
+    print(f"precision {prec}, no lens: bit-equal channels {same2:.5f}")
+    assert same2 >= 0.999
+
+
+def test_reference_default_render_c1(oracle):
+    """BASELINE.json configs[0] at its exact size: main.rs:30-56,126-127 - mars_texture_scene, 400 x 225, 100 spp, depth 50,
+    lens 0.4 deg - f64 parity mode against the oracle's reference-order render (image texture + lens: tolerance bar)."""
+    sc, cam = presets.mars_texture_scene(), presets.default_camera(400, 100, 50)
+    assert (cam.width, cam.height) == (400, 225)
+    lin, rgb8 = cam.render_arrays(sc, precision=abi.F64, seed=1)
+    o_lin, o_rgb8, o_seg, nan = oracle.render(sc.flat, cam.pod, abi.F64, seed=1, use_bvh=True, threads=8)
+    assert nan == 0
+    assert abs(cam.last_stats["segments"] - o_seg) <= 2e-4 * o_seg
+    err = np.abs(lin - o_lin)
+    assert float((err <= 1e-9 * (1 + np.abs(o_lin))).mean()) >= 0.999 and err.max() <= 0.05
+    assert float((rgb8 == o_rgb8).mean()) >= 0.9995 and int(np.abs(rgb8.astype(int) - o_rgb8.astype(int)).max()) <= 3
+
+
+def test_two_calls_on_one_handle_on_two_streams_are_ordered():
+    """A handle owns one work queue and one workspace: a second mirt_render_device on the same handle on another stream,
+    with nothing waiting in between, must come out right (the library orders it behind the first with an event) - before
+    the fix the second launch re-zeroed the queue head and overwrote the partial sums of the first."""
+    import torch
+
+    lib = abi.load()
+    sc = presets.bouncing_balls_scene(1)
+    ds = sc.device_scene(0)
+    cam_a, cam_b = presets.bouncing_balls_camera(320, 8, 50), presets.bouncing_balls_camera(256, 4, 50)
+    ref = {}
+    for k, cam in (("a", cam_a), ("b", cam_b)):
+        lin, _ = cam.render_arrays(sc, precision=abi.F32, seed=9)
+        ref[k] = torch.from_numpy(lin).cuda()
+    out_a = torch.zeros_like(ref["a"])
+    out_b = torch.zeros_like(ref["b"])
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    oa, ob = cam_a.opts(precision=abi.F32, seed=9), cam_b.opts(precision=abi.F32, seed=9)
+    torch.cuda.synchronize()
+    for _ in range(3):  # back to back, no host wait, alternating streams
+        abi.check(lib.mirt_render_device(ds.handle, C.byref(cam_a.pod), C.byref(oa), out_a.data_ptr(), None, s1.cuda_stream, None))
+        abi.check(lib.mirt_render_device(ds.handle, C.byref(cam_b.pod), C.byref(ob), out_b.data_ptr(), None, s2.cuda_stream, None))
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, ref["a"]) and torch.equal(out_b, ref["b"])
+    # a deferred call still has to be collected before the handle takes another launch
+    od = cam_b.opts(precision=abi.F32, seed=9, flags=abi.FLAG_DEFER_STATS)
+    abi.check(lib.mirt_render_device(ds.handle, C.byref(cam_b.pod), C.byref(od), out_b.data_ptr(), None, s2.cuda_stream, None))
+    assert lib.mirt_render_device(ds.handle, C.byref(cam_a.pod), C.byref(oa), out_a.data_ptr(), None, s1.cuda_stream, None) == -1
+    st = abi.MirtStats()
+    abi.check(lib.mirt_render_wait(ds.handle, C.byref(st)))
+    assert st.segments > 0
+
+
+def test_image_depends_on_arguments_only(monkeypatch):
+    """No entry point reads the environment: the variables round 1's library obeyed change nothing any more, and the
+    work-item size travels in mirt_opts."""
+    sc, cam = presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(128, 8, 20)
+    a, _ = cam.render_arrays(sc, precision=abi.F32, seed=4)
+    for k, v in (("MIRT_CHUNK", "4"), ("MIRT_GROUP_CHUNKS", "1"), ("MIRT_BROAD", "valu"), ("MIRT_BVH_KEEP", "3")):
+        monkeypatch.setenv(k, v)
+    assert cam.pass_granularity(precision=abi.F32) == 1 and cam.closest_hit_kind(sc, precision=abi.F32) == "matrix"
+    b, _ = cam.render_arrays(sc, precision=abi.F32, seed=4)
+    assert np.array_equal(bits(a), bits(b))
+    bad = cam.opts(precision=abi.F32)
+    bad._reserved[0] = 7
+    assert abi.load().mirt_closest_hit_kind(sc.device_scene(0).handle, C.byref(cam.pod), C.byref(bad)) == -1
