@@ -151,6 +151,7 @@ extern "C" {
     pub fn mirt_scene_destroy(scene: *mut mirt_scene);
     pub fn mirt_primary_hits(scene: *const mirt_scene, cam: *const mirt_camera, opts: *const mirt_opts, id: *mut u32, t: *mut c_void) -> c_int;
     pub fn mirt_render(scene: *const mirt_scene, cam: *const mirt_camera, opts: *const mirt_opts, rgb_linear: *mut c_void, rgb8: *mut u8, stats: *mut mirt_stats) -> c_int;
+    pub fn mirt_render_device_static(scene: *const mirt_scene, cam: *const mirt_camera, opts: *const mirt_opts, d_rgb_linear: *mut c_void, d_rgb8: *mut u8, stream: *mut c_void, stats: *mut mirt_stats) -> c_int;
     pub fn mirt_render_device(scene: *const mirt_scene, cam: *const mirt_camera, opts: *const mirt_opts, d_rgb_linear: *mut c_void, d_rgb8: *mut u8, stream: *mut c_void, stats: *mut mirt_stats) -> c_int;
     pub fn mirt_primary_hits_device(scene: *const mirt_scene, cam: *const mirt_camera, opts: *const mirt_opts, d_id: *mut u32, d_t: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn mirt_quantize_device(d_linear: *const c_void, precision: u32, n: usize, d_out: *mut u8, stream: *mut c_void, nan_count: *mut u64) -> c_int;

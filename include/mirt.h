@@ -210,6 +210,22 @@ int mirt_render_device(const mirt_scene* scene, const mirt_camera* cam, const mi
                        void* d_rgb_linear, uint8_t* d_rgb8, void* stream, mirt_stats* stats);
 int mirt_primary_hits_device(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
                              uint32_t* d_id, void* d_t, void* stream);
+/* mirt_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  It has NO counterpart in the reference (whose render allocates freely on the CPU); it exists only
+ * for those callers.  Same arguments, same kernels, same image bit for bit as mirt_render_device - but the launch's
+ * counters / work-queue head, its per-item partial sums and (MIRT_F64) its per-lane attenuation stacks live in a
+ * file-scope device array of MIRT_STATIC_SCRATCH_BYTES that each GPU the library runs on holds until the process ends,
+ * and the call makes no hipMalloc / hipFree / event or host allocation of any kind (everything else it needs was made by
+ * mirt_scene_create).  Limits: a call whose partial sums (3 reals per pixel of the part and chunk of samples, see
+ * mirt_pass_granularity; + 24 bytes x max_bounce_depth per lane of the grid in MIRT_F64) exceed the array is refused with
+ * MIRT_ERR_TOO_LARGE - e.g. 400x225x100 spp in f32 fits, 1920x1080x64 spp does not; a camera so far outside the scene
+ * that the matrix-pipe operands have to be rebuilt at another scale is refused with MIRT_ERR_INVALID until one
+ * mirt_render_device call has been made with it (or MIRT_FLAG_VALU_BROAD is passed).  With stats == NULL and without
+ * MIRT_FLAG_DEFER_STATS the call only enqueues one memset and two kernels on `stream`.
+ * ALL calls on one GPU share that GPU's array, whatever their scene handles: calls that overlap on one GPU race. */
+#define MIRT_STATIC_SCRATCH_BYTES (128ull << 20)
+int mirt_render_device_static(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
+                              void* d_rgb_linear, uint8_t* d_rgb8, void* stream, mirt_stats* stats);
 /* Waits for the render call made with MIRT_FLAG_DEFER_STATS on this scene handle (no reference counterpart: the
  * reference's render returns when the frame is done) and fills `stats` (may be NULL).  Until it has been called, further
  * render calls on the handle are refused; without the flag there is nothing to wait for and the call is an error. */

@@ -14,6 +14,7 @@ FLAG_BVH = 2  # closest hit through the bounding-ball tree (f32 only); same imag
 FLAG_DEFER_STATS = 8  # _device render calls: return at once, mirt_render_wait() collects the statistics
 FLAG_VALU_BROAD = 4  # f32 brute force: broad phase on the vector ALU instead of the matrix pipe; same image bit for bit
 FLAG_MX_SMALL = 16  # matrix-pipe broad phase also for scenes below its size threshold (tests, tuning); same image bit for bit
+STATIC_SCRATCH_BYTES = 128 << 20  # MIRT_STATIC_SCRATCH_BYTES: the device array behind mirt_render_device_static
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 TEX_SOLID, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 
@@ -126,6 +127,7 @@ EXPORTS = [
     "mirt_render_pass",
     "mirt_pass_granularity",
     "mirt_render_wait",
+    "mirt_render_device_static",
     "mirt_philox4x32_10",
 ]
 
@@ -179,6 +181,7 @@ def load():
     lib.mirt_render_pass.argtypes = [vp, P(MirtCamera), P(MirtOpts), u32, u32, vp, vp, vp, P(MirtStats)]
     lib.mirt_pass_granularity.argtypes = [P(MirtCamera), P(MirtOpts)]
     lib.mirt_pass_granularity.restype = u32
+    lib.mirt_render_device_static.argtypes = [vp, P(MirtCamera), P(MirtOpts), vp, vp, vp, P(MirtStats)]
     lib.mirt_render_wait.argtypes = [vp, P(MirtStats)]
     lib.mirt_render_wait.restype = C.c_int
     lib.mirt_closest_hit_kind.argtypes = [vp, P(MirtCamera), P(MirtOpts)]

@@ -503,15 +503,14 @@ static void choose_chunks(uint64_t n_pixels, uint32_t nsamples, size_t real_byte
  * hipMalloc; the one behind mirt_render_device_static is a fixed slice of a file-scope device array and never grows. */
 struct Workspace {
     DevStats* stats;
+    /* growing (the scene handle's own): */
     void** partial; size_t* partial_bytes;
     void** att; size_t* att_bytes;
-    bool fixed;
+    /* fixed (mirt_render_device_static): everything behind the header of this device's static array */
+    unsigned char* fixed_base; size_t fixed_cap;
 };
-static int ws_reserve(const Workspace& ws, void** buf, size_t* have, size_t need, const char* what) {
+static int ws_grow(void** buf, size_t* have, size_t need, const char* what) {
     if (need <= *have) return MIRT_OK;
-    if (ws.fixed)
-        return fail(MIRT_ERR_TOO_LARGE, std::string("mirt_render_device_static: ") + what + " need " + std::to_string(need) + " bytes, the static scratch has " +
-                                            std::to_string(*have) + " for them ");
     if (*buf) (void)hipFree(*buf); /* waits for the device: nothing in flight reads it any more */
     *buf = nullptr;
     *have = 0;
@@ -603,43 +602,90 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     rp.keep_num = 0;
     rp.att_lanes = 0;
     int rc;
-    size_t need = (size_t)rp.n_items * 3 * sizeof(R); /* one slot per queue position */
-    if ((rc = ws_reserve(ws, ws.partial, ws.partial_bytes, need, "the per-item partial sums"))) return rc;
+    const size_t need = (size_t)rp.n_items * 3 * sizeof(R); /* one slot per queue position */
+    R* partial = nullptr;
+    if (ws.fixed_base) {
+        if (need > ws.fixed_cap)
+            return fail(MIRT_ERR_TOO_LARGE, "mirt_render_device_static: the per-item partial sums of this call need " + std::to_string(need) +
+                                                " bytes, the static scratch has " + std::to_string(ws.fixed_cap) + " (MIRT_STATIC_SCRATCH_BYTES in mirt.h)");
+        partial = (R*)ws.fixed_base;
+    } else {
+        if ((rc = ws_grow(ws.partial, ws.partial_bytes, need, "the per-item partial sums"))) return rc;
+        partial = (R*)*ws.partial;
+    }
     if (cam->max_bounce_depth == 0) {
         /* color(ray, 0) is black before any hit test (camera.rs:269-271): no segment is traced */
-        HIP_TRY(hipMemsetAsync(*ws.partial, 0, need, st));
+        HIP_TRY(hipMemsetAsync(partial, 0, need, st));
     } else {
         /* persistent grid: as many blocks as can be resident, every wave pulls items until the queue is empty */
         const int per_cu = occupancy_of(render_fn(R(), bvh), (int)block);
         uint64_t waves_needed = ((uint64_t)rp.n_items + 63) / 64;
         uint64_t grid = std::min<uint64_t>((uint64_t)s->n_cus * per_cu, (waves_needed + waves_per_block - 1) / waves_per_block);
+        R* att = nullptr;
+        if (sizeof(R) == 8) {
+            /* parity mode multiplies a path's attenuations back to front like the reference's recursion (camera.rs:277): each
+             * lane keeps the attenuations of the path in hand in a stack of its own, [bounce][rgb][lane of the grid] */
+            const uint64_t per_block = (uint64_t)cam->max_bounce_depth * 3 * sizeof(R) * block;
+            if (ws.fixed_base) {
+                /* what the partial sums leave of the static array; the grid shrinks to the blocks whose stacks fit (any grid
+                 * size renders the same image, a smaller one only takes longer) */
+                const size_t used = (need + 255) & ~(size_t)255;
+                const uint64_t fit = used < ws.fixed_cap ? (ws.fixed_cap - used) / per_block : 0;
+                if (fit == 0)
+                    return fail(MIRT_ERR_TOO_LARGE, "mirt_render_device_static: no room left in the static scratch for the f64 attenuation stacks (" +
+                                                        std::to_string(per_block) + " bytes per block at max_bounce_depth " + std::to_string(cam->max_bounce_depth) + ")");
+                grid = std::min<uint64_t>(grid, fit);
+                att = (R*)(ws.fixed_base + used);
+            } else {
+                const uint64_t att_need = per_block * grid;
+                if (att_need > MIRT_ATT_STACK_LIMIT)
+                    return fail(MIRT_ERR_TOO_LARGE, "f64 parity mode keeps one attenuation per bounce and lane: max_bounce_depth " + std::to_string(cam->max_bounce_depth) +
+                                                        " needs " + std::to_string(att_need) + " bytes (limit 8 GiB)");
+                if ((rc = ws_grow(ws.att, ws.att_bytes, (size_t)att_need, "the f64 attenuation stacks"))) return rc;
+                att = (R*)*ws.att;
+            }
+            rp.att_lanes = (uint32_t)(grid * block);
+        }
         /* the last two full batches per wave are handed out one item per lane at a time */
         rp.tail_items = (uint32_t)std::min<uint64_t>(grid * waves_per_block * 2 * MIRT_QUEUE_BATCH, rp.n_items);
         if (bvh == 1 || bvh == 2) { /* suspend a traversal once this share (in 64ths) of the traversing lanes is all that is left (mirt_opts.bvh_keep) */
             rp.keep_num = bvh == 1 ? 32 : 16; /* measured: profiles/r01_microbench.txt */
             if (o->bvh_keep) rp.keep_num = o->bvh_keep;
         }
-        R* att = nullptr;
-        if (sizeof(R) == 8) {
-            /* parity mode multiplies a path's attenuations back to front like the reference's recursion (camera.rs:277): each
-             * lane keeps the attenuations of the path in hand in a stack of its own, [bounce][rgb][lane of the grid] */
-            rp.att_lanes = (uint32_t)(grid * block);
-            const uint64_t att_need = (uint64_t)cam->max_bounce_depth * 3 * sizeof(R) * rp.att_lanes;
-            if (att_need > MIRT_ATT_STACK_LIMIT)
-                return fail(MIRT_ERR_TOO_LARGE, "f64 parity mode keeps one attenuation per bounce and lane: max_bounce_depth " + std::to_string(cam->max_bounce_depth) +
-                                                    " needs " + std::to_string(att_need) + " bytes (limit 8 GiB)");
-            if ((rc = ws_reserve(ws, ws.att, ws.att_bytes, (size_t)att_need, "the f64 attenuation stacks"))) return rc;
-            att = (R*)*ws.att;
-        }
-        launch_render_kernel((uint32_t)grid, block, bvh, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, rp, (R*)*ws.partial, ws.stats, att);
+        launch_render_kernel((uint32_t)grid, block, bvh, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, rp, partial, ws.stats, att);
         HIP_TRY(hipGetLastError());
     }
     /* one wave per 64 pixels of a band row */
     const uint64_t rwaves = (uint64_t)part.local_rows * ((cam->img_width + 63u) / 64u);
     uint32_t rgrid = (uint32_t)((rwaves + MIRT_RESOLVE_WAVES - 1) / MIRT_RESOLVE_WAVES);
-    hipLaunchKernelGGL((resolve_kernel<R>), dim3(rgrid), dim3(MIRT_RESOLVE_WAVES * MIRT_WAVE), 0, st, (const R*)*ws.partial, dev_camera<R>(cam), part, rp, (uint32_t)n_pixels,
+    hipLaunchKernelGGL((resolve_kernel<R>), dim3(rgrid), dim3(MIRT_RESOLVE_WAVES * MIRT_WAVE), 0, st, (const R*)partial, dev_camera<R>(cam), part, rp, (uint32_t)n_pixels,
                        (R*)d_lin, d_rgb8, ws.stats, (R*)d_accum);
     HIP_TRY(hipGetLastError());
+    return MIRT_OK;
+}
+
+/* ---- the allocation-free entry point's memory (mirt_render_device_static) -----------------------------------------
+ * A file-scope device array: every GPU the library runs on holds its own copy, at its own address, until the process ends.
+ * In HOST code the array's name is only a stand-in for the symbol - never a device address - so the address is asked for
+ * once per device (static_scratch_ptr, called by mirt_scene_create with that device current) and everything below uses
+ * the pointer it returned.  Layout: [0, 4096) counters and work-queue head (DevStats), then the partial sums, then (f64)
+ * the attenuation stacks. */
+#define MIRT_STATIC_HEADER 4096u
+static_assert(sizeof(DevStats) <= MIRT_STATIC_HEADER, "header of the static scratch too small");
+static __device__ __align__(256) unsigned char mirt_static_scratch[MIRT_STATIC_SCRATCH_BYTES];
+#define MIRT_MAX_DEVICES 64
+static unsigned char* g_static_ptr[MIRT_MAX_DEVICES];
+static std::mutex g_static_mu;
+static int static_scratch_ptr(int device, unsigned char** out) { /* the calling thread's current device must be `device` */
+    if (device < 0 || device >= MIRT_MAX_DEVICES) return fail(MIRT_ERR_NO_DEVICE, "device index beyond MIRT_MAX_DEVICES");
+    std::lock_guard<std::mutex> g(g_static_mu);
+    if (!g_static_ptr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(mirt_static_scratch));
+        if (e != hipSuccess || !p) return fail(MIRT_ERR_HIP, std::string("hipGetSymbolAddress(mirt_static_scratch): ") + hipGetErrorString(e));
+        g_static_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_static_ptr[device];
     return MIRT_OK;
 }
 
@@ -801,6 +847,8 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_busy, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void**)&s->host_stats, sizeof(DevStats), hipHostMallocDefault);
         if (e != hipSuccess) { mirt_scene_destroy(s); return fail(MIRT_ERR_HIP, std::string("scene set-up: ") + hipGetErrorString(e)); }
+        unsigned char* sp = nullptr;
+        if ((rc = static_scratch_ptr(device, &sp))) { mirt_scene_destroy(s); return rc; }
         /* operands for a camera inside or near the scene (the scale then follows from the scene's extent alone) */
         mirt_camera c0;
         memset(&c0, 0, sizeof(c0));
@@ -944,12 +992,14 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
     const bool mx = use_mx(s, cam, o, &mx_e);
     if (mx && (rc = mx_ready(s, mx_set(s, o), mx_e, !use_static))) return rc; /* before the timed region: the first call at a new scale uploads operands */
     /* where the launch keeps its counters, partial sums and attenuation stacks */
-    unsigned char* sp = nullptr;
-    void *sp_partial = nullptr, *sp_att = nullptr;
-    size_t sp_partial_bytes = 0, sp_att_bytes = 0;
-    Workspace ws{s->stats, &s->partial, &s->partial_bytes, &s->att, &s->att_bytes, false};
+    Workspace ws{s->stats, &s->partial, &s->partial_bytes, &s->att, &s->att_bytes, nullptr, 0};
     if (use_static) {
-        return fail(MIRT_ERR_INVALID, "no static workspace in this build");
+        /* this device's copy of mirt_static_scratch, by the address taken at set-up (never the symbol's name): the header
+         * holds the counters and the queue head, launch_render places the partial sums and the f64 stacks behind it and
+         * refuses what does not fit; nothing is allocated */
+        unsigned char* sp = nullptr;
+        if ((rc = static_scratch_ptr(s->device, &sp))) return rc;
+        ws = Workspace{(DevStats*)sp, nullptr, nullptr, nullptr, nullptr, sp + MIRT_STATIC_HEADER, (size_t)(MIRT_STATIC_SCRATCH_BYTES - MIRT_STATIC_HEADER)};
     } else if (s->launched) {
         /* the previous launch on this handle - on whatever stream - owns the queue head, the counters and the workspace until
          * it is done: order this one behind it */
@@ -991,6 +1041,11 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
     }
     return rc;
 }
+int mirt_render_device_static(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, void* d_lin, uint8_t* d_rgb8, void* stream,
+                              mirt_stats* stats) {
+    return render_impl(s, cam, o, 0, 0xFFFFFFFFu, nullptr, d_lin, d_rgb8, stream, stats, true);
+}
+
 int mirt_primary_hits(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o, uint32_t* id, void* t) {
     int rc = check_common(s, cam, o);
     if (rc) return rc;
