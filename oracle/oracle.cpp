@@ -578,6 +578,29 @@ static V3<R> color_running_product(const Scene<R>& sc, Ray<R> ray, uint32_t dept
     return {thr.x * sky.x, thr.y * sky.y, thr.z * sky.z};
 }
 
+/* point3.rs:107-109: theta = Uniform(0, 2 pi), cos / sin.  double: the reference's expression through libm.  float: the f32
+ * spec's quarter-turn evaluation (DESIGN.md "Two precisions"; restated from the description in mirt_device.h, operation for
+ * operation): x = 4u, k = rint(x), y = (x - k) pi/2, Cephes sinf/cosf kernels on [-pi/4, pi/4], quadrant k mod 4. */
+static inline void lens_sincos(double u, double& s, double& c) {
+    const double TAU = 6.28318530717958647692528676655900577;
+    const double th = u * TAU;
+    c = std::cos(th);
+    s = std::sin(th);
+}
+static inline void lens_sincos(float u, float& s, float& c) {
+    const float x = u * 4.0f;
+    const float k = std::nearbyintf(x); /* round half to even, the default mode */
+    const float y = (x - k) * 1.57079632679489661923f;
+    const float z = y * y;
+    const float sp = std::fmaf(std::fmaf(std::fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * y, y);
+    const float cp = std::fmaf(std::fmaf(std::fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                               std::fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k & 3;
+    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = (q == 1 || q == 2) ? -cc : cc;
+}
+
 /* camera.rs:209-230 with the RNG contract: bounce 0, dims 0,1 -> AA (w,h), dims 2,3 -> disk (r,theta), dim 4 -> time. */
 template <class R> static inline Ray<R> ray_for(const Cam<R>& c, uint32_t wn, uint32_t hn, const Draws<R>& dr) {
     R ua = dr.dim(0), ub = dr.dim(1);
@@ -586,10 +609,10 @@ template <class R> static inline Ray<R> ray_for(const Cam<R>& c, uint32_t wn, ui
     V3<R> orig = c.lookfrom;
     if (!(c.defocus_angle <= (R)0.0)) { /* camera.rs:220-224, 261-264; point3.rs:106-110 */
         R uc = dr.dim(2), ud = dr.dim(3);
-        const R TAU = (R)6.28318530717958647692528676655900577;
         R r = std::sqrt(uc);
-        R th = ud * TAU;
-        R dx = r * std::cos(th), dy = r * std::sin(th);
+        R cs, sn;
+        lens_sincos(ud, sn, cs);
+        R dx = r * cs, dy = r * sn;
         orig = c.lookfrom + (c.disk_u * dx) + (c.disk_v * dy);
     }
     R ue = dr.dim(4);

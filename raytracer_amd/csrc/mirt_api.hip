@@ -934,6 +934,15 @@ static void print_diagnostics(const DevStats& h) {
                     (double)h.bvh_lane_steps / (double)(h.segments ? h.segments : 1), (double)h.bvh_wave_steps / (double)(h.wave_iters ? h.wave_iters : 1),
                     (double)h.bvh_leaf_rounds / (double)(h.wave_iters ? h.wave_iters : 1), (double)h.bvh_lane_leaves / (double)(h.segments ? h.segments : 1));
 #endif
+        {
+            static const char* dn[DG_N] = {"narrow round", "narrow: moving sphere", "narrow: roots (sqrt, near root)", "narrow: far root", "ray generation", "hit record + scatter",
+                                           "lambertian", "metal", "metal fuzz", "dielectric", "image texture", "checker texture", "sky", "store partial sum",
+                                           "deal items", "queue atomic", "-", "broad/narrow pass"};
+            const double wi = (double)(h.wave_iters ? h.wave_iters : 1), sg = (double)(h.segments ? h.segments : 1);
+            fprintf(stderr, "[mirt block counts] per wave-iteration: wave-level entries / lanes entering  (segments per wave-iteration %.2f)\n", sg / wi);
+            for (int i = 0; i < DG_N; ++i)
+                if (h.diag[i]) fprintf(stderr, "[mirt block counts]   %-32s %7.3f / %7.3f\n", dn[i], (double)h.diag[i] / wi, (double)h.diag[24 + i] / wi);
+        }
         double span = (double)(h.end_max - ~h.inv_start_max) * 1e-5; /* 100 MHz ticks -> ms */
         double life = (double)h.life_sum / (double)(h.n_waves ? h.n_waves : 1) * 1e-5;
         fprintf(stderr, "[mirt phase timing] %llu waves, first start -> last end %.3f ms, mean wave lifetime %.3f ms (%.1f%% of the span)\n",

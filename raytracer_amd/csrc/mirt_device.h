@@ -60,6 +60,33 @@ __device__ inline void m_sincos(double x, double& s, double& c) { sincos(x, &s, 
 __device__ inline float m_cos(float x) { return cosf(x); }
 __device__ inline double m_cos(double x) { return cos(x); }
 
+/* Lens sample angle theta = 2 pi u, u in [0,1) (point3.rs:107-109: `Uniform(0, 2 pi)`, then cos / sin).
+ *   double: the reference's own expression - th = u * TAU rounded once, then libm's sin/cos of it (OCML here, glibc in the
+ *           oracle: equal up to their last ulp).
+ *   float (f32 spec): sin and cos of the quarter-turn count x = 4u directly.  k = rint(x) and r = x - k in [-1/2, 1/2] are
+ *           exact in binary32, y = r * (pi/2) in [-pi/4, pi/4] goes through the two Cephes single-precision kernels
+ *           (|error| < 1e-7), and k mod 4 picks the quadrant.  Every step is an IEEE operation or an explicit fma, restated
+ *           one for one in the oracle's f32 instantiation: lens origins are bit-equal on both sides, and the routine costs
+ *           a fifth of OCML's sincosf with its argument reduction for arbitrary floats (119 VALU instructions per wave and
+ *           iteration of the render loop, 8 % of everything outside the broad phase). */
+__host__ __device__ inline void lens_sincos(float u, float& s, float& c) {
+    const float x = u * 4.0f;
+    const float k = __builtin_rintf(x);
+    const float y = (x - k) * 1.57079632679489661923f;
+    const float z = y * y;
+    const float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * y, y);
+    const float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                                    __builtin_fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k & 3; /* k in {0, ..., 4} */
+    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = (q == 1 || q == 2) ? -cc : cc;
+}
+__device__ inline void lens_sincos(double u, double& s, double& c) {
+    const double TAU = 6.28318530717958647692528676655900577;
+    sincos(u * TAU, &s, &c); /* one range reduction for both */
+}
+
 template <class R> __device__ inline V3<R> unit(V3<R> a) { return a / m_sqrt(dot(a, a)); } /* point3.rs:39-46 */
 template <class R> __device__ inline V3<R> reflect(V3<R> v, V3<R> n) { return v - (n * (R)2.0) * dot(v, n); } /* point3.rs:116-118 */
 

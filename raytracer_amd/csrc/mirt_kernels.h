@@ -80,6 +80,23 @@ template <class R> struct GeomGlobal {
     __device__ inline uint32_t material(uint32_t i) const { return sc.material[i]; }
 };
 
+/* Diagnostic build only (-DMIRT_PHASE_TIMING -DMIRT_BLOCK_COUNTS): wave-level execution counts of the divergent blocks of the segment loop
+ * (DevStats::diag[k] += 1 whenever at least one lane of a wave enters block k); printed by the host next to the phase cycles. */
+#ifdef MIRT_BLOCK_COUNTS /* a build of its own (with -DMIRT_PHASE_TIMING for the printing): the atomics distort the cycle split */
+#define MIRT_DIAG(sc, k, cond)                                                                                   \
+    do {                                                                                                         \
+        const unsigned long long b_ = __ballot(cond);                                                            \
+        if (b_ != 0ull && (cond) && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)b_) - 1)) {             \
+            atomicAdd((unsigned long long*)(sc).dbg + 9 + (k), 1ull);                                            \
+            atomicAdd((unsigned long long*)(sc).dbg + 9 + 24 + (k), (unsigned long long)__popcll(b_));           \
+        }                                                                                                        \
+    } while (0)
+#else
+#define MIRT_DIAG(sc, k, cond) do { } while (0)
+#endif
+enum { DG_NARROW_ROUND = 0, DG_NARROW_MOVING, DG_NARROW_ROOTS, DG_NARROW_FAR, DG_RAYGEN, DG_HIT, DG_LAMBERT, DG_METAL, DG_FUZZ, DG_GLASS, DG_IMAGE,
+       DG_CHECKER, DG_SKY, DG_STORE, DG_DEAL, DG_ATOMIC, DG_SCATTERED, DG_PASS, DG_N };
+
 /* exact per-candidate test: sphere.rs:91-101 against the interval (tmin, best.t), ties -> lowest hit id.  The hit
  * id of a sphere is only looked up on an exact tie in t (and once for the winner, by the caller). */
 template <class R, class G>
@@ -87,6 +104,7 @@ __device__ inline void narrow_test(const DevScene<R>& sc, const G& geo, uint32_t
     typename Vec4<R>::type sa = geo.a(i);
     V3<R> C = {sa.x, sa.y, sa.z};
     if (i >= sc.n_static) {
+        MIRT_DIAG(sc, DG_NARROW_MOVING, true);
         typename Vec4<R>::type sb = geo.b(i);
         C = center_at(C, V3<R>{sb.x, sb.y, sb.z}, ray.tm);
     }
@@ -98,6 +116,7 @@ __device__ inline void narrow_test(const DevScene<R>& sc, const G& geo, uint32_t
      * exactly when h*h is normal, so sqrt(d) <= -h: both roots (h -+ sqrt(d))/a are <= 0 < tmin.  Exact shortcut: it
      * rejects only what the root test below would reject, before paying for the sqrt and the two divisions. */
     if (h < -h_normal_min(h) && c > (R)0.0 && tmin >= (R)0.0) return;
+    MIRT_DIAG(sc, DG_NARROW_ROOTS, true);
     R sq = m_sqrt(d);
     /* strict interval (utils/interval.rs:37-39); an exact tie with the current best goes to the lower hit id
      * (never taken while there is no best: t < +inf is required, as in the reference) */
@@ -107,6 +126,7 @@ __device__ inline void narrow_test(const DevScene<R>& sc, const G& geo, uint32_t
     R t = (h - sq) / a;
     bool ok = inside(t);
     if (!ok) {
+        MIRT_DIAG(sc, DG_NARROW_FAR, true);
         t = (h + sq) / a;
         ok = inside(t);
     }
@@ -261,6 +281,14 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
  *     sphere side plus 160 eps |O|^2 on the ray side covers both (eps = 2^-24).  A diagnostic build
  *     (-DMIRT_VERIFY_BROAD) re-tests every pair exactly and counts misses: 0 on every workload in bench.py. */
 #define MIRT_RAY_SHRINK 0.99999f /* <= 1 - 160 * 2^-24 */
+/* The broad phases only FILTER (their survivors go through the exact test), so the ray-side constants need not be correctly
+ * rounded: v_rsq_f32 / v_sqrt_f32 (1 ulp) instead of sqrtf + division (~25 VALU instructions per ray and segment).  The
+ * normalised direction is then off by <= 2.5 eps instead of <= 2 eps, i.e. +1 eps ((|M|+|O|)^2) on h^2 - far inside the slack
+ * between the derived evaluation errors (40 eps / 50.4 eps) and the margins carried (160 eps / 256 eps); the -DMIRT_VERIFY_BROAD
+ * build still counts 0 misses (profiles/r02_microbench.txt). */
+__device__ inline float filter_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ inline double filter_rsq(double x) { return 1.0 / sqrt(x); }
+__device__ inline float filter_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 /* LDS of an f32 block: ONE block of 16 waves per CU (4 waves per SIMD), so that one copy of the scene serves them all.
  *   resident scenes (<= MIRT_LDS_RECORDS spheres): bounding records S for the broad phase, exact records A, B and
@@ -317,7 +345,7 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
     best.idx = 0xFFFFFFFFu;
     const V3<float> O = ray.o;
     const float a_true = ray_a(ray.d);
-    const float inv = 1.0f / sqrtf(a_true);
+    const float inv = filter_rsq(a_true);
     const V3<float> Dn = {ray.d.x * inv, ray.d.y * inv, ray.d.z * inv};
     const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
     /* an inactive lane gets k2 = +inf: q = -inf, never a candidate */
@@ -545,12 +573,12 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
     /* ---- the ray's operands ---- */
     mirt_h8 bgx, bgy, bex, bey;
     {
-        const R inv = (R)1.0 / m_sqrt(a_true);
+        const R inv = filter_rsq(a_true);
         const V3<float> Dn = {(float)(ray.d.x * inv), (float)(ray.d.y * inv), (float)(ray.d.z * inv)};
         const V3<float> O = {(float)(ray.o.x * (R)sc.mx_scale), (float)(ray.o.y * (R)sc.mx_scale), (float)(ray.o.z * (R)sc.mx_scale)};
         const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
         const float o2 = __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x));
-        const float k2 = o2 * MIRT_MX_SHRINK - __builtin_fmaf(MIRT_MX_FLOOR_LIN, sqrtf(o2), MIRT_MX_FLOOR_ABS);
+        const float k2 = o2 * MIRT_MX_SHRINK - __builtin_fmaf(MIRT_MX_FLOOR_LIN, filter_sqrt(o2), MIRT_MX_FLOOR_ABS);
         const bool ok = o2 <= MIRT_MX_K2MAX; /* false for NaN */
         _Float16 dhx, dlx, dhy, dly, dhz, dlz, k1h, k1l, ohx, olx, ohy, oly, ohz, olz, k2h, k2l;
         mx_split(Dn.x, dhx, dlx); mx_split(Dn.y, dhy, dly); mx_split(Dn.z, dhz, dlz); mx_split(-k1, k1h, k1l);
@@ -644,6 +672,7 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
             flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull; /* no room for another tile */
         }
         pt.stamp(PH_BROAD);
+        MIRT_DIAG(sc, DG_PASS, active);
         /* ---- narrow phase: as in trace_cons ---- */
         {
             uint32_t k = 0, m = 0, gi = 0;
@@ -655,6 +684,7 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
                     gi = (gbase + (e.x >> 16)) * MIRT_CGROUP + (MIRT_CGROUP - 1);
                 }
                 if (__ballot(m != 0) == 0ull) break;
+                MIRT_DIAG(sc, DG_NARROW_ROUND, m != 0);
                 if (m != 0) {
                     const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
                     m &= m - 1u;
@@ -793,7 +823,7 @@ __device__ inline void trace_bvh_resume(const DevScene<float>& sc, const Store& 
                                         float tmin, Closest<float>& best, BvhState& st, uint32_t keep, uint32_t& narrow_count, PhaseTimer& pt) {
     const V3<float> O = ray.o;
     const float a_true = ray_a(ray.d);
-    const float inv = 1.0f / sqrtf(a_true);
+    const float inv = filter_rsq(a_true);
     const V3<float> Dn = {ray.d.x * inv, ray.d.y * inv, ray.d.z * inv};
     const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
     const float o2 = __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x));
@@ -801,7 +831,7 @@ __device__ inline void trace_bvh_resume(const DevScene<float>& sc, const Store& 
     const V3<float> O2 = {O.x * 2.0f, O.y * 2.0f, O.z * 2.0f};
     /* slab constants: the per-ray widening delta = s |O| (rounded up), 1/D with |1/D| capped (D = 0 -> 1e30: a
      * parallel ray gets +-huge parameters of the right sign instead of inf - inf) */
-    const float delta = sqrtf(o2) * (MIRT_BVH_S * 1.0001f) + 1e-30f;
+    const float delta = filter_sqrt(o2) * (MIRT_BVH_S * 1.0001f) + 1e-30f;
     const V3<float> Op = {O.x + delta, O.y + delta, O.z + delta}, Om = {O.x - delta, O.y - delta, O.z - delta};
     auto cap_inv = [](float d) {
         const float r = 1.0f / d;
@@ -1046,6 +1076,7 @@ template <class R> __device__ inline uint32_t to_u32_sat(R x) { /* Rust `as u32`
 template <class R> __device__ inline V3<R> lambertian_attenuation(const DevScene<R>& sc, const DevMaterial<R>& m, const Hit<R>& h) {
     if (m.tex_kind == MIRT_TEX_SOLID) return m.albedo; /* texture.rs:24-28 */
     if (m.tex_kind == MIRT_TEX_CHECKER) {              /* texture.rs:46-59 */
+        MIRT_DIAG(sc, DG_CHECKER, true);
         uint32_t acc = (uint32_t)floor_to_i32(m_floor(h.p.x * m.inv_scale));
         acc += (uint32_t)floor_to_i32(m_floor(h.p.y * m.inv_scale));
         acc += (uint32_t)floor_to_i32(m_floor(h.p.z * m.inv_scale));
@@ -1053,6 +1084,7 @@ template <class R> __device__ inline V3<R> lambertian_attenuation(const DevScene
     }
     /* IMAGE: texture.rs:71-94 with (u,v) of sphere.rs:72-76 */
     if (m.img_h == 0) return V3<R>{(R)0.0, (R)1.0, (R)1.0} / m.reflectance;
+    MIRT_DIAG(sc, DG_IMAGE, true);
     const R PI = (R)3.14159265358979323846264338327950288;
     const R FRAC_1_PI = (R)0.318309886183790671537767526745028724;
     R theta = -m_acos(h.on.y);
@@ -1095,6 +1127,7 @@ __device__ inline bool scatter(const DevScene<R>& sc, const DevMaterial<R>& m, c
     R ua, ub, uc, ud; /* dims 0..3 of this bounce */
     dr.dims0123(ua, ub, uc, ud);
     if (m.kind == MIRT_MAT_LAMBERTIAN) { /* material.rs:59-84; dims: 0 = absorb test, 1..3 = vector */
+        MIRT_DIAG(sc, DG_LAMBERT, true);
         if (!(ua < m.reflectance)) return false;
         V3<R> dir = hit.n + unit(V3<R>{ub, uc, ud}); /* positive-octant quirk of point3.rs:88-93 */
         const R e = (R)1e-8;
@@ -1104,6 +1137,8 @@ __device__ inline bool scatter(const DevScene<R>& sc, const DevMaterial<R>& m, c
         return true;
     }
     if (m.kind == MIRT_MAT_METAL) { /* material.rs:97-114; dims 0..2 = vector */
+        MIRT_DIAG(sc, DG_METAL, true);
+        MIRT_DIAG(sc, DG_FUZZ, m.has_fuzz != 0);
         V3<R> refl = reflect(rin.d, hit.n);
         if (m.has_fuzz) refl = unit(refl) + unit(V3<R>{ua, ub, uc}) * m.fuzz;
         out = {hit.p, refl, rin.tm};
@@ -1112,6 +1147,7 @@ __device__ inline bool scatter(const DevScene<R>& sc, const DevMaterial<R>& m, c
     }
     /* DIELECTRIC material.rs:126-154; dim 0 (the reference short-circuits the draw away under total internal
      * reflection; with a counter RNG an unused draw changes nothing) */
+    MIRT_DIAG(sc, DG_GLASS, true);
     att = {(R)1.0, (R)1.0, (R)1.0};
     R ri = hit.front ? (R)1.0 / m.ior : m.ior;
     V3<R> udir = unit(rin.d);
@@ -1132,11 +1168,9 @@ template <class R> __device__ inline RayT<R> ray_for(const DevCamera<R>& c, uint
     V3<R> px = c.px00 + (c.du * ((R)wn + ox)) + (c.dv * ((R)hn + oy));
     V3<R> orig = c.lookfrom;
     if (!(c.defocus_angle <= (R)0.0)) {
-        const R TAU = (R)6.28318530717958647692528676655900577;
         R r = m_sqrt(uc);
-        R th = ud * TAU;
         R sn, cs;
-        m_sincos(th, sn, cs); /* one range reduction for both */
+        lens_sincos(ud, sn, cs); /* theta = 2 pi ud */
         R dx = r * cs, dy = r * sn;
         orig = c.lookfrom + (c.disk_u * dx) + (c.disk_v * dy);
     }
@@ -1185,6 +1219,7 @@ struct DevStats { /* device-side counters, one atomic per wave at kernel end */
     unsigned long long life_sum;        /* sum over waves of (end - start) */
     unsigned long long n_waves;
     unsigned long long bvh_lane_steps, bvh_wave_steps, bvh_leaf_rounds, bvh_lane_leaves; /* -DMIRT_PHASE_TIMING -DMIRT_BVH_COUNTERS */
+    unsigned long long diag[48]; /* -DMIRT_PHASE_TIMING: MIRT_DIAG, [k] wave-level entries of block k, [24 + k] lanes that entered it */
 };
 
 template <class R> __device__ inline R wave_sum_u(R v) {
@@ -1333,6 +1368,7 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
     for (;;) {
         /* ---- deal work items to idle lanes ---------------------------------------------------------- */
         const unsigned long long idle = __ballot(!has_work);
+        MIRT_DIAG(sc, DG_DEAL, !has_work && !(exhausted && q_next == q_end));
         if (idle != 0ull && !(exhausted && q_next == q_end)) {
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
@@ -1349,6 +1385,7 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                  * once the queue order below keeps a glass pixel's chunks out of one wave.) */
                 const uint32_t batch = q_end + rp.tail_items >= rp.n_items ? MIRT_WAVE : MIRT_QUEUE_BATCH;
                 uint32_t base = 0;
+                MIRT_DIAG(sc, DG_ATOMIC, lane == 0);
                 if (lane == 0) base = atomicAdd(&stats->queue_head, batch);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= rp.n_items) {
@@ -1403,6 +1440,7 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
 #endif
         pt.stamp(PH_QUEUE);
         /* ---- camera ray for lanes that start a sample (camera.rs:209-230 / 248-252) ------------------- */
+        MIRT_DIAG(sc, DG_RAYGEN, need_ray);
         if (need_ray) {
             thr = {(R)1.0, (R)1.0, (R)1.0};
             depth_left = cam.depth;
@@ -1439,6 +1477,8 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
             ++n_seg;
             bool done;
             V3<R> radiance = {(R)0.0, (R)0.0, (R)0.0};
+            MIRT_DIAG(sc, DG_HIT, best.idx != 0xFFFFFFFFu);
+            MIRT_DIAG(sc, DG_SKY, best.idx == 0xFFFFFFFFu);
             if (best.idx != 0xFFFFFFFFu) {
                 Hit<R> hit = tr.hit(best, ray);
                 ++bounce;
@@ -1481,6 +1521,7 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 if (sample < s_end) {
                     need_ray = true; /* regenerate: this lane starts its next sample in the next iteration */
                 } else {
+                    MIRT_DIAG(sc, DG_STORE, true);
                     size_t o = (size_t)item * 3;
                     partial[o] = acc.x;
                     partial[o + 1] = acc.y;

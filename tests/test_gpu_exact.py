@@ -90,6 +90,19 @@ def test_f32_radiance_bit_exact_against_the_f32_spec(oracle, plain_balls, accel)
         assert np.array_equal(rgb8, o_rgb8)
 
 
+def test_f32_radiance_bit_exact_with_the_lens(oracle, plain_balls):
+    """The thin-lens sample of the f32 spec (mirt_device.h::lens_sincos: quarter-turn reduction + two polynomial kernels, every
+    step an IEEE operation) is restated in the oracle's f32 instantiation, so the bench camera - lens 0.4 deg, shutter times,
+    moving spheres - is bit-exact in f32 as long as no image texture is hit."""
+    sc, cam = plain_balls, presets.bouncing_balls_camera(160, 12, 50)
+    assert cam.pod.defocus_angle > 0
+    for accel in (None, "valu"):
+        lin, rgb8 = cam.render_arrays(sc, precision=abi.F32, seed=6, accel=accel)
+        o_lin, o_rgb8, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F32, seed=6, threads=8, spec_chunk=cam.pass_granularity(precision=abi.F32))
+        assert cam.last_stats["segments"] == o_seg
+        assert np.array_equal(bits(lin), bits(o_lin)) and np.array_equal(rgb8, o_rgb8)
+
+
 @pytest.mark.parametrize("prec", [abi.F64, abi.F32])
 def test_stress_scene_radiance_bit_exact(oracle, prec):
     """2 000 static spheres of all three materials (the C5 generator; no texture, no lens), streaming-tile kernels."""
