@@ -26,6 +26,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)": 256 CU x 4 SIMD x 32 lanes x 2 x 2.4 GHz
+FP64_VALU_PEAK_TFLOPS = 78.6
+NOMINAL_CLOCK_GHZ = 2.4  # the clock both nominal peaks are quoted at; under this load the chip runs at ~2.0 GHz (profiles/*_sq_pmc.txt)
+SIMDS_PER_CU = 4
+# Issue slots of the matrix-pipe broad phase that no schedule can avoid: per wave and tile of 32 spheres
+# 4 x v_mfma_f32_32x32x16_f16 (8 passes = 32 cycles each) and, per (ray, sphere) pair, one v_fma_f32 and one v_alignbit_b32
+# (64 wave-instructions of 2 cycles); the matrix core and the vector ALU of a SIMD do not run side by side
+# (bench/mfma_overlap.hip), so the cycles add.  Per segment, the `5` of SURVEY 8d (a = D.D) is 3 more instructions.
+MX_CYCLES_PER_WAVE_TILE = 4 * 32 + 64 * 2
+MX_CYCLES_PER_WAVE_SEGMENT = 3 * 2
+PROFILE_TAGS = {("balls1080p", 1): "r02_mx", ("balls1080p", 0): "r02_valu", ("stress10000", 1): "r02_stress10k", ("stress10000", 0): "r02_stress10k_valu",
+                ("textured", 0): "r02_textured"}
+
+
+def profile_traffic(tag, kernel):
+    """HBM bytes per launch of `kernel` from the committed counter passes profiles/<tag>_hbm_traffic.txt (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, tools/profile.sh).  Calibration (MI355X_MICROARCH.md: FETCH_SIZE halves WIDE
+    streaming reads, other patterns are to be calibrated on a known byte count): resolve_kernel reads the partial sums K2
+    wrote exactly once - WRITE_SIZE of K2 771.4 MiB, FETCH_SIZE of resolve 739.6 MiB raw - so for the access patterns of
+    these kernels the raw FETCH_SIZE is the byte count (factor 1.04, not 2); applied as 1."""
+    path = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.txt")
+    if not os.path.exists(path):
+        return None
+    vals = {}
+    for line in open(path):
+        if kernel in line and " raw " in line:
+            f = line.split()
+            c = "FETCH_SIZE" if "FETCH_SIZE" in f else "WRITE_SIZE" if "WRITE_SIZE" in f else None
+            if c:
+                vals[c] = float(f[f.index("raw") + 1]) * 1024.0  # the last launch of the run
+    if len(vals) != 2:
+        return None
+    return {"bytes": vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "fetch": vals["FETCH_SIZE"], "write": vals["WRITE_SIZE"], "file": f"profiles/{tag}_hbm_traffic.txt"}
+
+
+def profile_valu_rate(tag):
+    """VALU wave-instructions per SIMD-cycle from the committed SQ pass profiles/<tag>_sq_pmc.txt (tools/pmc_report.py line)."""
+    path = os.path.join(ROOT, "profiles", f"{tag}_sq_pmc.txt")
+    if not os.path.exists(path):
+        return None
+    for line in open(path):
+        if "VALU wave-instructions per SIMD-cycle" in line:
+            try:
+                return float(line.split(":")[-1].split()[0])
+            except ValueError:
+                return None
+    return None
 
 
 def build_workload(name, width, spp, depth):
@@ -41,6 +87,22 @@ def build_workload(name, width, spp, depth):
         n = int(name[6:] or 10000)
         return presets.stress_scene(n, 1), presets.stress_camera(width, spp, depth), f"stress({n})"
     raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline_c1(seed):
+    """BASELINE.json configs[0], the reference's own default render (main.rs:30-56,126-127): mars_texture_scene, 400 x 225,
+    100 spp, depth 50, lens 0.4 deg - the WHOLE frame on one thread (the reference is single-threaded), f64 oracle with the
+    reference's BVH walk."""
+    from oracle import binding as ob
+    from raytracer_amd import abi, presets
+
+    sc, cam = presets.mars_texture_scene(), presets.default_camera(400, 100, 50)
+    t0 = time.perf_counter()
+    _, _, seg, _ = ob.render(sc.flat, cam.pod, abi.F64, seed=seed, use_bvh=True, threads=1, want_rgb8=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(seg / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port", "seconds_per_frame": round(dt, 3),
+            "sample": f"the reference's default render in full: mars_texture_scene {cam.width}x{cam.height}x100spp depth 50, {seg} segments in {dt:.1f} s, "
+                      "f64 oracle with the reference's BVH walk, single thread"}, sc, cam
 
 
 def cpu_baseline(scene, cam, seed, seconds_budget=12.0):
@@ -102,6 +164,12 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the gather path with a process group of one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets N ranks rehearse the N>1 path on ONE GPU")
     args = ap.parse_args()
+
+    # stdout carries ONE JSON line and nothing else: librccl prints a version banner to fd 1 when the process group is made,
+    # so everything written to fd 1 before the result goes to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
 
@@ -169,10 +237,19 @@ def main():
         sl.allb = torch.zeros((world * rows0, W, 3), dtype=real, device="cuda") if use_dist else None
         sl.frame = torch.zeros((H, W, 3), dtype=real, device="cuda") if rank == 0 else None
         sl.busy = False
+        # gloo rehearsal (N ranks on one GPU): the gather goes through pinned host copies made on the frame's own stream - torch's
+        # gloo backend must never be handed a device tensor here (tools/gloo_probe.py: its device staging deadlocks while the
+        # producing stream is busy, flushed or not; host tensors are fine)
+        host_gather = use_dist and args.backend != "nccl"
+        sl.hband = torch.empty((rows0, W, 3), dtype=real, pin_memory=True) if host_gather else None
+        sl.hall = torch.empty((world * rows0, W, 3), dtype=real, pin_memory=True) if host_gather else None
+        sl.copied = torch.cuda.Event() if host_gather else None
+        sl.gather_pending = False
         ring.append(sl)
     band, band8 = ring[0].band, ring[0].band8
     torch.cuda.synchronize()
     stats = []
+    gather_events = []  # (before, after) of every gather, on the slot's stream
 
     def collect(sl):
         if sl.busy:
@@ -180,6 +257,16 @@ def main():
             abi.check(lib.mirt_render_wait(sl.ds.handle, C.byref(st)))
             sl.busy = False
             stats.append(st)
+        if sl.gather_pending:
+            # rehearsal: the frame's band has reached pinned memory behind its kernels; gather on the host, send the frame back.
+            # It happens when the slot is recycled (or at the fence), so the frames of the other slots stay in flight meanwhile.
+            sl.copied.synchronize()
+            td.all_gather_into_tensor(sl.hall, sl.hband)
+            with torch.cuda.stream(sl.stream):
+                sl.allb.copy_(sl.hall, non_blocking=True)
+            if rank == 0:
+                abi.check(lib.mirt_deinterleave_device(sl.allb.data_ptr(), sl.band.numel() * sl.band.element_size(), world, S, W, H, elem, sl.frame.data_ptr(), sl.stream.cuda_stream))
+            sl.gather_pending = False
 
     def step(f):
         sl = ring[f % depth]
@@ -187,11 +274,18 @@ def main():
         q = sl.stream.cuda_stream
         abi.check(lib.mirt_render_device(sl.ds.handle, C.byref(cam.pod), C.byref(opts), sl.band.data_ptr(), sl.band8.data_ptr(), q, None))
         sl.busy = True
-        if use_dist:
-            if args.backend != "nccl":
-                sl.stream.synchronize()  # rehearsal only: torch's gloo all-gather of a device tensor hangs on this image while its stream is busy (tools/gloo_probe.py)
+        if use_dist and args.backend != "nccl":
             with torch.cuda.stream(sl.stream):
+                sl.hband.copy_(sl.band, non_blocking=True)
+                sl.copied.record()
+            sl.gather_pending = True
+        elif use_dist:
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(sl.stream):
+                g0.record()
                 dist.gather_bands_into(sl.allb, sl.band)  # RCCL all-gather over xGMI: the one exchange step
+                g1.record()
+            gather_events.append((g0, g1))
             if rank == 0:
                 abi.check(lib.mirt_deinterleave_device(sl.allb.data_ptr(), sl.band.numel() * sl.band.element_size(), world, S, W, H, elem, sl.frame.data_ptr(), q))
         else:
@@ -211,6 +305,7 @@ def main():
         step(f)
     fence()
     stats.clear()
+    gather_events.clear()
     t0 = time.perf_counter()
     for f in range(args.steps):
         step(f)
@@ -227,21 +322,82 @@ def main():
     iters = sum(s.wave_iterations for s in stats)
     narrow = sum(s.narrow_tests for s in stats)
     if td is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        rdev = "cuda" if args.backend == "nccl" else "cpu"  # the reductions of the report: gloo gets host tensors only
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
-        v = torch.tensor([seg, flops, iters, narrow], dtype=torch.float64, device="cuda")
+        v = torch.tensor([seg, flops, iters, narrow], dtype=torch.float64, device=rdev)
         td.all_reduce(v, op=td.ReduceOp.SUM)
         seg_all, flops_all, iters_all, narrow_all = (float(x) for x in v.tolist())
+        # per-rank view for reading a scaling record: this rank's band kernel and its gather (event time on the slot's stream:
+        # with frames in flight it includes waiting for the slowest rank's band, which is what a gather costs a rank)
+        mine = torch.tensor([kern_ms / max(1, len(stats)), sum(a.elapsed_time(b) for a, b in gather_events) / max(1, len(gather_events)), float(seg)],
+                            dtype=torch.float64, device=rdev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        td.all_gather(per_rank, mine)
+        per_rank = [t_.tolist() for t_ in per_rank]
     else:
+        per_rank = None
         seg_all, flops_all, iters_all, narrow_all = float(seg), float(flops), float(iters), float(narrow)
 
     if rank == 0:
         # rank 0's kernel: per-GPU rate.  With frames in flight the launches share the chip (each one's event time spans
         # its neighbours' too), so the rate is priced with this rank's share of the wall time instead: a lower bound.
         achieved = (flops / ((kern_ms if depth == 1 else elapsed * 1e3) * 1e-3)) / 1e12 if kern_ms > 0 else 0.0
+        tiny = scene.flat.n_spheres <= 8 and kind == 0
+        kernel_name = ["render_kernel_f32_tiny" if tiny else "render_kernel_f32", "render_kernel_f32_mx", "render_kernel_f32_bvh(_lds)", "render_kernel_f64<2>", "render_kernel_f64_mx"][kind]
+        n_launch = max(1, len(stats))
+        ms_avg = kern_ms / n_launch
+        t_priced = (kern_ms if depth == 1 else elapsed * 1e3) * 1e-3  # s; with frames in flight the launches overlap: wall time, a lower bound
+        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        measured_peak = C.c_double(0.0)
+        if lib.mirt_measure_fma_peak(local_rank, C.byref(measured_peak)) != 0:
+            measured_peak.value = 0.0
+        tag = PROFILE_TAGS.get((args.workload, kind)) if (W, cam.pod.samples_per_pixel, world) in ((1920, 64, 1), (3840, 16, 1), (3840, 256, 1)) else None
+        traffic = profile_traffic(tag, kernel_name) if tag else None
+        roof = {"kernel": kernel_name, "kernel_ms_avg": round(ms_avg, 3), "flops_per_segment": round(flops / max(seg, 1), 1),
+                "algorithmic_tflops": round(achieved, 3),
+                "traffic": traffic["bytes"] if traffic else None,
+                "traffic_source": (traffic["file"] + " (FETCH_SIZE raw + WRITE_SIZE of the last launch; calibration in bench.py::profile_traffic)") if traffic else None,
+                "traffic_algorithmic": W * H * 3 * (4 if args.precision == 32 else 8),
+                "traffic_note": "algorithmic = the linear RGB frame written once (+ 4 B per image-textured bounce, L2-resident); the measured bytes are the per-work-item partial "
+                                "sums K2 writes for K2b to add in a fixed order (12 B x W x H x chunks): wasted traffic by the HBM yardstick, 0.25 ms of the frame, the price of "
+                                "an image that does not depend on scheduling or GPU count"}
+        note = ("algorithmic flops = 18/static sphere test + 27/moving sphere test + 5/segment (SURVEY.md 8d); rank 0's launches; duration = HIP events around each launch on its own stream"
+                + ("" if depth == 1 else f"; {depth} frames in flight: launches overlap, priced with this rank's wall time of the timed region"))
+        if kind in (1, 4):
+            # the kernel whose broad phase runs on the matrix pipe is bounded by the issue slots of the SIMD's shared VALU/MFMA port
+            n_static = int(round(sum(s_.static_tests for s_ in stats) / max(seg, 1)))
+            n_moving = int(round(sum(s_.moving_tests for s_ in stats) / max(seg, 1)))
+            slots = ((n_static + 3) // 4 * 4 + n_moving + 31) // 32 * 32  # the library's layout: statics padded to 4, the whole array to 32-sphere tiles
+            tiles = slots // 32
+            cyc = tiles * MX_CYCLES_PER_WAVE_TILE + MX_CYCLES_PER_WAVE_SEGMENT
+            t_bound = (seg / 64.0) * cyc / (cus * SIMDS_PER_CU * NOMINAL_CLOCK_GHZ * 1e9)  # s for all timed launches of this rank
+            peak = flops / t_bound / 1e12
+            roof.update({"bound": "valu+mfma issue", "achieved": round(achieved, 3), "peak": round(peak, 3), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                         "issue_cycles_per_wave_and_segment": cyc, "sphere_tiles": tiles, "clock_ghz": NOMINAL_CLOCK_GHZ, "simds": cus * SIMDS_PER_CU,
+                         "bound_ms_per_launch": round(t_bound / n_launch * 1e3, 3),
+                         "vs_fp32_valu_peak": round(achieved / FP32_VALU_PEAK_TFLOPS, 4)})
+            note += (f"; bound = mandatory issue slots of the matrix-pipe broad phase: per wave and segment {tiles} tiles x (4 MFMA x 32 + 64 VALU x 2 cycles) + 6 = {cyc} SIMD-cycles, "
+                     f"segments / 64 waves, {cus * SIMDS_PER_CU} SIMDs at the nominal {NOMINAL_CLOCK_GHZ} GHz; `peak` is that bound expressed in the same algorithmic flops, so frac = bound time / kernel time; "
+                     "`vs_fp32_valu_peak` is the algorithmic rate against the vector-ALU peak alone, which this kernel can exceed because 7 of the 9 VALU operations per pair moved to the "
+                     "matrix pipe - the metric's '% of FP32 VALU peak' is `valu_broad.frac` (render_kernel_f32, every pair on the vector ALU)")
+        elif kind == 2:
+            roof.update({"bound": "latency (tree walk; no brute-force flops)", "achieved": None, "peak": None, "unit": "TFLOP/s", "frac": None})
+        elif tiny:
+            rate = profile_valu_rate(tag) if tag else None
+            roof.update({"bound": "valu issue (per-segment shading, RNG and texture gather: SURVEY.md 8d reports VALU utilisation here, not a flop fraction)",
+                         "achieved": rate, "peak": 0.5, "unit": "VALU wave-instructions per SIMD-cycle", "frac": round(rate / 0.5, 4) if rate else None,
+                         "achieved_source": f"profiles/{tag}_sq_pmc.txt" if rate else None,
+                         "vs_fp32_valu_peak": round(achieved / FP32_VALU_PEAK_TFLOPS, 4)})
+        else:
+            pk = FP32_VALU_PEAK_TFLOPS if args.precision == 32 else FP64_VALU_PEAK_TFLOPS
+            roof.update({"bound": "valu_fp32" if args.precision == 32 else "valu_fp64", "achieved": round(achieved, 3), "peak": pk, "unit": "TFLOP/s", "frac": round(achieved / pk, 4)})
+        roof["peak_fp32_valu_nominal"] = FP32_VALU_PEAK_TFLOPS
+        roof["peak_fp32_valu_measured"] = round(measured_peak.value, 1) if measured_peak.value else None
+        roof["note"] = note + "; peak_fp32_valu_measured = independent v_fma_f32 chains at 8 waves/SIMD on this box (mirt_measure_fma_peak)"
         out = {
-            "metric": "Mrays/s at 1080p (ray segment = one closest-hit query) + % of FP32 VALU peak",
+            "metric": "Mrays/s at 1080p (ray segment = one closest-hit query); % of FP32 VALU peak = valu_broad.frac (all-VALU brute-force kernel, same frame, same image)",
             "value": round(seg_all / elapsed / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -263,22 +419,15 @@ def main():
                                 "bounding-ball tree (MIRT_FLAG_BVH)", "brute-force tile loop, f64",
                                 "brute-force tile loop, f64: f32 broad phase on the matrix pipe, exact f64 narrow phase and shading"][kind],
             },
-            "roofline": {
-                "bound": "valu_fp32",
-                "achieved": round(achieved, 3),
-                "peak": FP32_VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
-                # HBM bytes per launch of this kernel, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE in separate passes
-                # (profiles/r01_mx_hbm_traffic.txt: 17-35 MiB fetched + 772 MiB written, the per-item partial sums; not re-measured by this script).  Only quoted for the workload it was taken on.
-                "traffic": 8.3e8 if (args.workload == "balls1080p" and (W, cam.pod.samples_per_pixel, world) == (1920, 64, 1) and kind in (0, 1)) else None,
-                "kernel": ["render_kernel_f32_tiny" if scene.flat.n_spheres <= 8 else "render_kernel_f32", "render_kernel_f32_mx", "render_kernel_f32_bvh(_lds)", "render_kernel_f64<2>", "render_kernel_f64_mx"][kind],
-                "kernel_ms_avg": round(kern_ms / max(1, len(stats)), 3),
-                "flops_per_segment": round(flops / max(seg, 1), 1),
-                "note": "algorithmic flops = 18/static sphere test + 27/moving sphere test + 5/segment (SURVEY.md 8d); rank 0's launches; duration = HIP events around each launch on its own stream"
-                        + ("" if depth == 1 else f"; {depth} frames in flight: launches overlap, `achieved` = this rank's flops / wall time of the timed region")
-                        + ("; every (ray, sphere) pair is still tested, but the two dot products of the broad phase run on the matrix pipe, so the "
-                           "algorithmic rate can exceed the vector-ALU peak it is priced against (DESIGN.md 5c; `valu_broad` below is the all-VALU kernel)" if kind == 1 else ""),
+            "roofline": roof,
+            "multi_gpu": None if per_rank is None else {
+                "rccl_ranks": world, "backend": args.backend, "exchange": "all_gather_into_tensor of the f32 RGB bands, then K4 (mirt_deinterleave_device) on rank 0",
+                "band_bytes_per_rank": int(rows0 * W * elem),
+                "band_kernel_ms_per_rank": [round(r_[0], 3) for r_ in per_rank],
+                "gather_ms_per_rank": [round(r_[1], 3) for r_ in per_rank],
+                "segments_per_rank": [int(r_[2]) for r_ in per_rank],
+                "note": "band_kernel_ms = HIP-event time of the rank's render launch (frames in flight overlap: a launch's events span its neighbours); "
+                        "gather_ms = events around the collective on the frame's stream",
             },
             "diagnostics": {
                 "segments_per_step": seg_all / args.steps,
@@ -319,9 +468,12 @@ def main():
                 abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(o3), band.data_ptr(), band8.data_ptr(), stream, C.byref(st3)))
                 ms3.append(st3.kernel_ms)
             fl3 = 18 * st3.static_tests + 27 * st3.moving_tests + 5 * st3.segments
+            tf3 = fl3 / (min(ms3) * 1e-3) / 1e12
             out["valu_broad"] = {"value": round(st3.segments / (min(ms3) * 1e-3) / 1e6, 3), "unit": "Mrays/s", "kernel": "render_kernel_f32", "kernel_ms": round(min(ms3), 3),
-                                 "frac": round(fl3 / (min(ms3) * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4),
-                                 "note": "same frame, same image, broad phase on the vector ALU: fraction of the FP32 VALU peak in the same algorithmic flops"}
+                                 "bound": "valu_fp32", "achieved": round(tf3, 3), "peak": FP32_VALU_PEAK_TFLOPS, "frac": round(tf3 / FP32_VALU_PEAK_TFLOPS, 4),
+                                 "frac_of_measured_peak": round(tf3 / measured_peak.value, 4) if measured_peak.value else None,
+                                 "note": "same frame, same image, every (ray, sphere) pair on the vector ALU: the metric's % of FP32 VALU peak, in the algorithmic flops of SURVEY.md 8d "
+                                         "(against the nominal 157.3 TFLOP/s and against this box's measured FMA peak)"}
         if world == 1 and args.accel == "brute" and args.precision == 32 and not args.no_extras:
             # not the metric: the same frame through the bounding-volume tree (MIRT_FLAG_BVH), bit-identical image
             o2 = cam.opts(precision=32, seed=args.seed, strip_rows=S, part_index=0, part_count=1, flags=abi.FLAG_COMPACT_ROWS | abi.FLAG_BVH)
@@ -350,7 +502,20 @@ def main():
             base, mt = cpu_baseline(scene, cam, args.seed, args.cpu_seconds)
             out["cpu_baseline"] = base
             out["cpu_baseline_all_cores"] = mt
-        print(json.dumps(out), flush=True)
+            # BASELINE.json configs[0]: the reference's own default render, whole frame, CPU single thread - and the same frame on the GPU
+            c1, sc1, cam1 = cpu_baseline_c1(args.seed)
+            st1 = abi.MirtStats()
+            ms1 = []
+            o1 = cam1.opts(precision=64, seed=args.seed)
+            ds1 = sc1.device_scene(local_rank)
+            f1 = torch.zeros((cam1.height, cam1.width, 3), dtype=torch.float64, device="cuda")
+            for _ in range(3):
+                abi.check(lib.mirt_render_device(ds1.handle, C.byref(cam1.pod), C.byref(o1), f1.data_ptr(), None, stream, C.byref(st1)))
+                ms1.append(st1.kernel_ms)
+            c1["gpu_same_frame"] = {"precision": "f64 (parity mode)", "kernel_ms": round(min(ms1), 3), "value": round(st1.segments / (min(ms1) * 1e-3) / 1e6, 1), "unit": "Mrays/s"}
+            out["cpu_baseline_c1"] = c1
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if td is not None:
         td.barrier()
         td.destroy_process_group()

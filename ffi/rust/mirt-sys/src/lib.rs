@@ -145,6 +145,7 @@ const _: () = assert!(std::mem::size_of::<mirt_stats>() == 72);
 
 extern "C" {
     pub fn mirt_abi_version() -> c_int;
+    pub fn mirt_measure_fma_peak(device: c_int, tflops: *mut f64) -> c_int;
     pub fn mirt_device_count() -> c_int;
     pub fn mirt_last_error() -> *const c_char;
     pub fn mirt_scene_create(desc: *const mirt_scene_desc, device: c_int, out: *mut *mut mirt_scene) -> c_int;

@@ -272,6 +272,11 @@ uint32_t mirt_part_rows(uint32_t height, uint32_t strip_rows, uint32_t part_inde
  * broad phase on the matrix pipe; negative = MIRT_ERR_* for invalid arguments. */
 int mirt_closest_hit_kind(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts);
 
+/* Measurement helper (no reference counterpart; SURVEY.md 8d asks for the FP32 vector peak "measured on the box by an FMA
+ * microbenchmark" next to the nominal figure): runs independent v_fma_f32 chains on every SIMD of `device` at 8 waves per
+ * SIMD for a few milliseconds and returns the rate in TFLOP/s (2 flop per lane and instruction). */
+int mirt_measure_fma_peak(int device, double* tflops);
+
 /* Counter-based RNG, exposed for known-answer tests: Philox4x32-10 block.  out[4]. */
 void mirt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

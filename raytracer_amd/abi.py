@@ -129,6 +129,7 @@ EXPORTS = [
     "mirt_render_wait",
     "mirt_render_device_static",
     "mirt_philox4x32_10",
+    "mirt_measure_fma_peak",
 ]
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -186,6 +187,7 @@ def load():
     lib.mirt_render_wait.restype = C.c_int
     lib.mirt_closest_hit_kind.argtypes = [vp, P(MirtCamera), P(MirtOpts)]
     lib.mirt_closest_hit_kind.restype = C.c_int
+    lib.mirt_measure_fma_peak.argtypes = [C.c_int, P(C.c_double)]
     lib.mirt_philox4x32_10.argtypes = [P(u32), P(u32), P(u32)]
     lib.mirt_philox4x32_10.restype = None
     _lib = lib

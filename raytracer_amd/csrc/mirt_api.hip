@@ -1145,6 +1145,38 @@ int mirt_render_pass(const mirt_scene* s, const mirt_camera* cam, const mirt_opt
     return rc;
 }
 
+int mirt_measure_fma_peak(int device, double* tflops) {
+    if (!tflops) return fail(MIRT_ERR_INVALID, "null argument");
+    *tflops = 0.0;
+    int ndev = mirt_device_count();
+    if (device < 0 || device >= ndev) return fail(MIRT_ERR_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, iters = 4096, reps = 5;
+    const int blocks = cus * 8; /* 256 threads = one wave per SIMD; 8 blocks per CU */
+    float* out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipMalloc((void**)&out, 4));
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0.f;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(fma_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, out, 1.0001f, 0.5f, iters); /* warm-up: clocks, code upload */
+        e = hipEventRecord(e0, nullptr);
+        for (int r = 0; r < reps && e == hipSuccess; ++r) hipLaunchKernelGGL(fma_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, out, 1.0001f, 0.5f, iters);
+        if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    if (e != hipSuccess || !(ms > 0.f)) return fail(MIRT_ERR_HIP, std::string("fma peak: ") + hipGetErrorString(e));
+    *tflops = (double)reps * 2.0 * 16.0 * iters * (double)blocks * 256.0 / ((double)ms * 1e-3) / 1e12;
+    return MIRT_OK;
+}
+
 int mirt_quantize_device(const void* d_linear, uint32_t precision, size_t n, uint8_t* d_out, void* stream, uint64_t* nan_count) {
     if (!d_linear || !d_out) return fail(MIRT_ERR_INVALID, "null argument");
     if (precision != MIRT_F32 && precision != MIRT_F64) return fail(MIRT_ERR_INVALID, "precision must be 32 or 64");

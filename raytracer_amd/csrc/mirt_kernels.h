@@ -1757,6 +1757,23 @@ template <class R> __global__ void quantize_kernel(const R* __restrict__ lin, si
     if (nan && nan_count) atomicAdd(nan_count, 1ull);
 }
 
+/* ---- measurement: the FP32 vector peak of the box (mirt_measure_fma_peak) --------------------------------------- */
+__global__ __launch_bounds__(256) void fma_peak_kernel(float* out, float a, float b, int iters) {
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = (float)(threadIdx.x + i);
+    /* both constants in VGPRs: a VALU instruction with an SGPR source issues at half rate on gfx950 (bench/sgpr_rate.hip) */
+    asm volatile("" : "+v"(a), "+v"(b));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = __builtin_fmaf(x[i], a, b);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += x[i];
+    if (s == 123.456f) out[0] = s; /* keeps the chains alive */
+}
+
 /* ---- K4: gathered bands -> frame.  One thread per unit of 16, 4 or 1 bytes: the widest that divides a row and the band
  *      stride and matches the pointers' alignment (chosen by the host). ------------------------------------------------ */
 template <class U>
