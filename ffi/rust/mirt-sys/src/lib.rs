@@ -128,6 +128,29 @@ pub struct mirt_stats {
     pub tree_segments: u64,
 }
 
+pub const MIRT_NODE_MAX_DEVICES: usize = 16;
+pub const MIRT_GATHER_TO_ROOT: u32 = 0;
+pub const MIRT_GATHER_ALLGATHER: u32 = 1;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct mirt_node_stats {
+    pub segments: u64,
+    pub nan_pixels: u64,
+    pub n_devices: u32,
+    pub gather: u32,
+    pub wall_ms: f64,
+    pub gather_ms: f64,
+    pub scatter_ms: f64,
+    pub band_kernel_ms: [f64; MIRT_NODE_MAX_DEVICES],
+    pub band_segments: [u64; MIRT_NODE_MAX_DEVICES],
+}
+
+#[repr(C)]
+pub struct mirt_node {
+    _opaque: [u8; 0],
+}
+
 #[repr(C)]
 pub struct mirt_scene {
     _opaque: [u8; 0],
@@ -146,6 +169,11 @@ const _: () = assert!(std::mem::size_of::<mirt_stats>() == 72);
 extern "C" {
     pub fn mirt_abi_version() -> c_int;
     pub fn mirt_measure_fma_peak(device: c_int, tflops: *mut f64) -> c_int;
+    pub fn mirt_node_create(desc: *const mirt_scene_desc, device_ids: *const c_int, n_devices: u32, out: *mut *mut mirt_node) -> c_int;
+    pub fn mirt_node_destroy(node: *mut mirt_node);
+    pub fn mirt_node_device_count(node: *const mirt_node) -> u32;
+    pub fn mirt_node_render(node: *mut mirt_node, cam: *const mirt_camera, opts: *const mirt_opts, gather: u32, rgb_linear: *mut c_void, rgb8: *mut u8, stats: *mut mirt_node_stats) -> c_int;
+    pub fn mirt_node_render_device(node: *mut mirt_node, cam: *const mirt_camera, opts: *const mirt_opts, gather: u32, d_rgb_linear: *mut c_void, d_rgb8: *mut u8, stats: *mut mirt_node_stats) -> c_int;
     pub fn mirt_device_count() -> c_int;
     pub fn mirt_last_error() -> *const c_char;
     pub fn mirt_scene_create(desc: *const mirt_scene_desc, device: c_int, out: *mut *mut mirt_scene) -> c_int;

@@ -272,6 +272,42 @@ uint32_t mirt_part_rows(uint32_t height, uint32_t strip_rows, uint32_t part_inde
  * broad phase on the matrix pipe; negative = MIRT_ERR_* for invalid arguments. */
 int mirt_closest_hit_kind(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts);
 
+/* ---- one host thread, N GPUs of one node (SURVEY.md 8b "one host thread drives N devices", 8e) ---------------------
+ * What a drop-in Camera::render (src/camera/camera.rs:232) calls to use the whole node: the scene is replicated on every
+ * device of `device_ids`, the frame is cut into interleaved strips of mirt_opts.strip_rows rows (strip s -> device
+ * s mod N), every device renders its band with the kernels of mirt_render_device, the bands meet on the root
+ * (device_ids[0]) in ONE exchange over xGMI with RCCL (single process, ncclCommInitAll) and K4 scatters them into frame
+ * order.  The image is mirt_render's bit for bit, whatever N and whichever exchange.  RCCL is loaded at run time on the
+ * first node render (librccl.so.1); single-GPU entry points never touch it. */
+#define MIRT_NODE_MAX_DEVICES 16u
+typedef enum mirt_gather_kind {
+    MIRT_GATHER_TO_ROOT = 0,  /* grouped ncclSend / ncclRecv: every peer sends its band to the root over its own xGMI link */
+    MIRT_GATHER_ALLGATHER = 1 /* ncclAllGather (ring): every device ends up with all bands; only the root's copy is used */
+} mirt_gather_kind;
+typedef struct mirt_node_stats {
+    uint64_t segments;   /* of the whole frame */
+    uint64_t nan_pixels;
+    uint32_t n_devices;
+    uint32_t gather;     /* mirt_gather_kind of this call */
+    double wall_ms;      /* host clock around the call */
+    double gather_ms;    /* HIP events on the root's stream around the exchange (includes waiting for the slowest band) */
+    double scatter_ms;   /* K4 on the root */
+    double band_kernel_ms[MIRT_NODE_MAX_DEVICES]; /* per device: HIP-event time of its render launch */
+    uint64_t band_segments[MIRT_NODE_MAX_DEVICES];
+} mirt_node_stats;
+typedef struct mirt_node mirt_node;
+int mirt_node_create(const mirt_scene_desc* desc, const int* device_ids, uint32_t n_devices, mirt_node** out);
+void mirt_node_destroy(mirt_node* node);
+uint32_t mirt_node_device_count(const mirt_node* node);
+/* Host buffers, full frames (rgb_linear: W*H*3 reals, rgb8: W*H*3 bytes; either may be NULL, not both).  When only rgb8 is
+ * asked for, the bands travel as bytes (a quarter of the f32 traffic).  opts: precision, seed, flags (closest-hit front end),
+ * strip_rows and the tuning fields are honoured; part_index / part_count must be left 0 (the node partitions). */
+int mirt_node_render(mirt_node* node, const mirt_camera* cam, const mirt_opts* opts, uint32_t gather,
+                     void* rgb_linear, uint8_t* rgb8, mirt_node_stats* stats);
+/* The same with DEVICE pointers on the root device. */
+int mirt_node_render_device(mirt_node* node, const mirt_camera* cam, const mirt_opts* opts, uint32_t gather,
+                            void* d_rgb_linear, uint8_t* d_rgb8, mirt_node_stats* stats);
+
 /* Measurement helper (no reference counterpart; SURVEY.md 8d asks for the FP32 vector peak "measured on the box by an FMA
  * microbenchmark" next to the nominal figure): runs independent v_fma_f32 chains on every SIMD of `device` at 8 waves per
  * SIMD for a few milliseconds and returns the rate in TFLOP/s (2 flop per lane and instruction). */

@@ -108,6 +108,24 @@ class MirtStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+NODE_MAX_DEVICES = 16
+GATHER_TO_ROOT, GATHER_ALLGATHER = 0, 1  # mirt_gather_kind: grouped ncclSend/ncclRecv to the root | ncclAllGather
+
+
+class MirtNodeStats(C.Structure):
+    _fields_ = [
+        ("segments", C.c_uint64),
+        ("nan_pixels", C.c_uint64),
+        ("n_devices", C.c_uint32),
+        ("gather", C.c_uint32),
+        ("wall_ms", C.c_double),
+        ("gather_ms", C.c_double),
+        ("scatter_ms", C.c_double),
+        ("band_kernel_ms", C.c_double * NODE_MAX_DEVICES),
+        ("band_segments", C.c_uint64 * NODE_MAX_DEVICES),
+    ]
+
+
 # every symbol include/mirt.h declares (tests/test_abi.py checks the built library exports them all)
 EXPORTS = [
     "mirt_abi_version",
@@ -130,6 +148,11 @@ EXPORTS = [
     "mirt_render_device_static",
     "mirt_philox4x32_10",
     "mirt_measure_fma_peak",
+    "mirt_node_create",
+    "mirt_node_destroy",
+    "mirt_node_device_count",
+    "mirt_node_render",
+    "mirt_node_render_device",
 ]
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -187,6 +210,13 @@ def load():
     lib.mirt_render_wait.restype = C.c_int
     lib.mirt_closest_hit_kind.argtypes = [vp, P(MirtCamera), P(MirtOpts)]
     lib.mirt_closest_hit_kind.restype = C.c_int
+    lib.mirt_node_create.argtypes = [P(MirtSceneDesc), P(C.c_int), u32, P(vp)]
+    lib.mirt_node_destroy.argtypes = [vp]
+    lib.mirt_node_destroy.restype = None
+    lib.mirt_node_device_count.argtypes = [vp]
+    lib.mirt_node_device_count.restype = u32
+    lib.mirt_node_render.argtypes = [vp, P(MirtCamera), P(MirtOpts), u32, vp, vp, P(MirtNodeStats)]
+    lib.mirt_node_render_device.argtypes = [vp, P(MirtCamera), P(MirtOpts), u32, vp, vp, P(MirtNodeStats)]
     lib.mirt_measure_fma_peak.argtypes = [C.c_int, P(C.c_double)]
     lib.mirt_philox4x32_10.argtypes = [P(u32), P(u32), P(u32)]
     lib.mirt_philox4x32_10.restype = None

@@ -288,6 +288,28 @@ class DeviceScene:
             pass
 
 
+class NodeScene:
+    """Owns a mirt_node: one scene replica, stream and band buffer per GPU of `devices`; the root is devices[0]."""
+
+    def __init__(self, flat: FlatScene, devices: Sequence[int]):
+        self.flat = flat
+        self.devices = list(devices)
+        self.handle = C.c_void_p()
+        ids = (C.c_int * len(self.devices))(*self.devices)
+        abi.check(abi.load().mirt_node_create(C.byref(flat.desc), ids, len(self.devices), C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            abi.load().mirt_node_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- camera (camera/camera.rs) ------------------------------------------------------------------------
 class InitError(Exception):
     """InitError::Antialiaser (camera.rs:26-29).  Uniform::new(-0.5, 0.5) cannot fail, so never raised today."""
@@ -420,6 +442,23 @@ class Camera:
             )
         )
         self.last_stats = st.asdict()
+        return lin, rgb8
+
+    def render_arrays_node(self, node: "NodeScene", precision=None, seed=None, want_linear=True, want_rgb8=True, accel=None,
+                           gather=abi.GATHER_TO_ROOT, strip_rows=0):
+        """render_arrays on all GPUs of `node` (mirt_node_render: interleaved strips, one RCCL exchange, K4 on the root);
+        the same image bit for bit.  Returns (linear, rgb8); self.last_stats holds the per-device figures."""
+        prec = self.precision if precision is None else precision
+        H, W = self.height, self.width
+        lin = np.empty((H, W, 3), dtype=np.float64 if prec == abi.F64 else np.float32) if want_linear else None
+        rgb8 = np.empty((H, W, 3), dtype=np.uint8) if want_rgb8 else None
+        st = abi.MirtNodeStats()
+        o = self.opts(precision=prec, seed=seed, flags=_accel_flags(accel), strip_rows=strip_rows, part_count=0)
+        abi.check(abi.load().mirt_node_render(node.handle, C.byref(self.pod), C.byref(o), gather,
+                                              None if lin is None else lin.ctypes.data, None if rgb8 is None else rgb8.ctypes.data, C.byref(st)))
+        n = st.n_devices
+        self.last_stats = {"segments": st.segments, "n_devices": n, "gather": st.gather, "wall_ms": st.wall_ms, "gather_ms": st.gather_ms,
+                           "scatter_ms": st.scatter_ms, "band_kernel_ms": list(st.band_kernel_ms[:n]), "band_segments": list(st.band_segments[:n])}
         return lin, rgb8
 
     def pass_granularity(self, precision=None) -> int:

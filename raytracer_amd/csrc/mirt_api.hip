@@ -22,6 +22,7 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+void mirt_internal_set_error(const char* msg) { g_err = msg ? msg : ""; } /* for mirt_node.hip */
 #define HIP_TRY(expr)                                                                                     \
     do {                                                                                                  \
         hipError_t e_ = (expr);                                                                           \

@@ -1,0 +1,68 @@
+"""mirt_node_* - one host thread, N GPUs inside libmirt.so, RCCL exchange - on the GPUs this box has (the
+round's box has ONE: RCCL then runs with a communicator of one rank; the band bookkeeping for N > 1 is covered by the
+partition tests of test_gpu_parity.py and the gloo test of test_dist.py).  Needs a GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, presets
+from raytracer_amd.api import NodeScene
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+@pytest.fixture(scope="module")
+def node_and_scene():
+    sc = presets.bouncing_balls_scene(1)
+    n_gpus = min(abi.load().mirt_device_count(), 8)
+    node = NodeScene(sc.flat, list(range(n_gpus)))
+    yield node, sc, n_gpus
+    node.close()
+
+
+@pytest.mark.parametrize("gather", [abi.GATHER_TO_ROOT, abi.GATHER_ALLGATHER])
+@pytest.mark.parametrize("prec", [abi.F32, abi.F64])
+def test_node_render_equals_single_gpu_render(node_and_scene, gather, prec):
+    node, sc, n = node_and_scene
+    cam = presets.bouncing_balls_camera(200, 6, 50)
+    ref, ref8 = cam.render_arrays(sc, precision=prec, seed=4)
+    seg = cam.last_stats["segments"]
+    lin, rgb8 = cam.render_arrays_node(node, precision=prec, seed=4, gather=gather)
+    st = cam.last_stats
+    assert st["n_devices"] == n and st["gather"] == gather and st["segments"] == seg == sum(st["band_segments"])
+    assert np.array_equal(bits(lin), bits(ref)) and np.array_equal(rgb8, ref8)
+    assert st["gather_ms"] > 0 and all(ms > 0 for ms in st["band_kernel_ms"])
+    # bytes only: the bands travel as u8
+    _, only8 = cam.render_arrays_node(node, precision=prec, seed=4, gather=gather, want_linear=False)
+    assert np.array_equal(only8, ref8)
+
+
+def test_node_render_odd_sizes_and_front_ends(node_and_scene):
+    node, sc, _ = node_and_scene
+    for w, spp, strip, accel in ((97, 3, 3, "bvh"), (33, 0, 1, "valu"), (250, 2, 16, None)):
+        cam = presets.bouncing_balls_camera(w, spp, 12)
+        ref, ref8 = cam.render_arrays(sc, precision=abi.F32, seed=2, accel=accel)
+        lin, rgb8 = cam.render_arrays_node(node, precision=abi.F32, seed=2, accel=accel, strip_rows=strip, gather=abi.GATHER_TO_ROOT)
+        assert np.array_equal(bits(lin), bits(ref)) and np.array_equal(rgb8, ref8)
+
+
+def test_node_argument_errors(node_and_scene):
+    node, sc, _ = node_and_scene
+    lib = abi.load()
+    cam = presets.bouncing_balls_camera(64, 1, 5)
+    out = np.zeros((cam.height, cam.width, 3), np.uint8)
+    o = cam.opts(precision=abi.F32, part_index=0, part_count=2)
+    assert lib.mirt_node_render(node.handle, C.byref(cam.pod), C.byref(o), abi.GATHER_TO_ROOT, None, out.ctypes.data, None) == -1
+    o = cam.opts(precision=abi.F32, part_count=0)
+    assert lib.mirt_node_render(node.handle, C.byref(cam.pod), C.byref(o), 7, None, out.ctypes.data, None) == -1
+    assert lib.mirt_node_render(node.handle, C.byref(cam.pod), C.byref(o), abi.GATHER_TO_ROOT, None, None, None) == -1
+    h = C.c_void_p()
+    ids = (C.c_int * 2)(0, 0)
+    assert lib.mirt_node_create(C.byref(sc.flat.desc), ids, 2, C.byref(h)) == -1 and b"distinct" in lib.mirt_last_error()
+    ids = (C.c_int * 1)(99)
+    assert lib.mirt_node_create(C.byref(sc.flat.desc), ids, 1, C.byref(h)) == -2
