@@ -138,6 +138,61 @@ def cpu_baseline(scene, cam, seed, seconds_budget=12.0):
     return base, mt
 
 
+def run_node(args, lib, scene, cam, scene_name, result_fd):
+    """--node: the whole node from ONE process through mirt_node_render_device (what a drop-in Camera::render would call)."""
+    import torch
+
+    from raytracer_amd import abi
+    from raytracer_amd.api import NodeScene
+
+    n = args.gpus
+    if n > torch.cuda.device_count():
+        raise SystemExit(f"--node --gpus {n}: this box has {torch.cuda.device_count()} GPU(s)")
+    node = NodeScene(scene.flat, list(range(n)))
+    H, W = cam.height, cam.width
+    real = torch.float32 if args.precision == 32 else torch.float64
+    frame = torch.zeros((H, W, 3), dtype=real, device="cuda:0")
+    accel_flags = {"brute": 0, "valu": abi.FLAG_VALU_BROAD, "bvh": abi.FLAG_BVH}[args.accel]
+    cam.chunk_samples, cam.group_chunks = args.chunk, args.group_chunks
+    o = cam.opts(precision=args.precision, seed=args.seed, flags=accel_flags, part_count=0, bvh_keep=args.bvh_keep)
+    kinds = {"to_root": abi.GATHER_TO_ROOT, "allgather": abi.GATHER_ALLGATHER}
+
+    def run(kind, steps):
+        sts = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st = abi.MirtNodeStats()
+            abi.check(lib.mirt_node_render_device(node.handle, C.byref(cam.pod), C.byref(o), kinds[kind], frame.data_ptr(), None, C.byref(st)))
+            sts.append(st)
+        return time.perf_counter() - t0, sts
+
+    run(args.gather, max(1, args.warmup) + 1)  # set-up (communicators, buffers, operands) and warm-up, untimed
+    elapsed, sts = run(args.gather, args.steps)
+    other = "allgather" if args.gather == "to_root" else "to_root"
+    run(other, 1)
+    el2, sts2 = run(other, max(2, args.steps // 2))
+    seg = sum(s_.segments for s_ in sts)
+
+    def view(sl):
+        k = len(sl)
+        return {"gather_ms": round(sum(s_.gather_ms for s_ in sl) / k, 3), "scatter_ms": round(sum(s_.scatter_ms for s_ in sl) / k, 3),
+                "band_kernel_ms_per_device": [round(sum(s_.band_kernel_ms[i] for s_ in sl) / k, 3) for i in range(n)],
+                "call_ms": round(sum(s_.wall_ms for s_ in sl) / k, 3)}
+
+    out = {
+        "metric": "Mrays/s at 1080p (ray segment = one closest-hit query)", "value": round(seg / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": n,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic (seeded restatement of the reference's scenes)",
+        "config": {"workload": f"{scene_name}: {scene.flat.n_spheres} spheres, {W}x{H}, {cam.pod.samples_per_pixel} spp, depth {cam.pod.max_bounce_depth}",
+                   "parallelism": f"one process, {n} GPU(s): mirt_node_render_device (scene replicas, interleaved 8-row strips, RCCL {args.gather} inside libmirt.so, K4 on device 0)",
+                   "frames_in_flight": 1, "seed": args.seed},
+        "multi_gpu": {"rccl_ranks": n, "single_process": True, "exchange": args.gather, **view(sts), "other_exchange": {"kind": other, "ms_per_step": round(el2 / len(sts2) * 1e3, 3), **view(sts2)}},
+    }
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
+    node.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +216,10 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames in flight (ring of scene handles and streams); 1 = one frame at a time; 0 = 1 on one GPU "
                          "(each launch alone on the chip: the kernel duration the roofline is priced with), 3 on several")
+    ap.add_argument("--node", action="store_true",
+                    help="single process: drive --gpus N devices through the library's own multi-GPU entry point (mirt_node_render_device: scene replicas, "
+                         "RCCL exchange inside libmirt.so) instead of one torch.distributed rank per GPU; prints one line of the same shape")
+    ap.add_argument("--gather", default="to_root", choices=["to_root", "allgather"], help="--node: the exchange that is timed (the other one is measured beside it)")
     ap.add_argument("--force-dist", action="store_true", help="run the gather path with a process group of one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets N ranks rehearse the N>1 path on ONE GPU")
     args = ap.parse_args()
@@ -203,6 +262,8 @@ def main():
 
     lib = abi.load()
     scene, cam, scene_name = build_workload(args.workload, args.width, args.spp, args.depth)
+    if args.node:
+        return run_node(args, lib, scene, cam, scene_name, result_fd)
     ds = scene.device_scene(local_rank)
     H, W, S = cam.height, cam.width, dist.DEFAULT_STRIP_ROWS
     real = torch.float32 if args.precision == 32 else torch.float64

@@ -5,10 +5,12 @@
  * (/root/reference/src/scene/image_loader.rs:5-8), which goes through `image 0.25.5` -> `zune-jpeg 0.4.14`.
  * That decoder is a third-party dependency and is not restated here; this one implements ITU-T T.81 directly:
  * sequential Huffman DCT (SOF0 / SOF1, 8-bit), 1 or 3 components, sampling factors 1..2 (chroma replicated),
- * restart intervals, JFIF YCbCr -> RGB.  The inverse DCT is evaluated in double precision and rounded once, so
- * every sample is within +-1 of any IEEE 1180-compliant integer IDCT (libjpeg, zune-jpeg) before colour conversion;
- * tests/test_host_cpp.py compares against libjpeg (PIL) on synthetic images and, where the reference is present,
- * on its two textures.  PARITY UNPINNED against zune-jpeg itself.  Progressive files are refused with an error.
+ * restart intervals, JFIF YCbCr -> RGB.  Inverse DCT and colour conversion are the fixed-point forms of the IJG decoders
+ * (LL&M factorisation with 13-bit constants; 16-bit colour constants), so a 4:4:4 file decodes to the bytes libjpeg /
+ * libjpeg-turbo produce: tests/test_host_cpp.py compares against libjpeg (PIL) on synthetic images and, where the
+ * reference is present, on its two textures (equal byte for byte).  zune-jpeg, the reference's decoder, is an
+ * IEEE 1180-class integer IDCT as well, but it is not available here: PARITY UNPINNED against zune-jpeg itself.
+ * Subsampled chroma is replicated (libjpeg smooths it by default).  Progressive files are refused with an error.
  *
  * Also reads binary PPM (P6), the format __graft_entry__.build() exports the pre-decoded textures in.
  */
@@ -106,29 +108,49 @@ static const uint8_t ZIGZAG[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 2
                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-/* ideal separable 8x8 inverse DCT (T.81 A.3.3) in double, + level shift, one rounding, clamp */
+/* 8x8 inverse DCT: the Loeffler-Ligtenberg-Moschytz factorisation (ICASSP 1989, 12 multiplies per 1-D pass) in the fixed-point
+ * form every IJG-derived decoder uses - 13-bit constants, two extra bits kept between the passes, one rounding per pass - so that
+ * the samples are the ones libjpeg / libjpeg-turbo ("islow") produce, not merely within +-1 of them: a +-1 difference per
+ * component grows to +-4 in RGB through the colour matrix, which is what round 1's floating-point IDCT showed against libjpeg. */
+inline int descale(long x, int n) { return (int)((x + (1L << (n - 1))) >> n); }
+inline void idct_1d(const long in[8], long out[8]) { /* in: 8 coefficients; out: 8 samples scaled by 2^13 */
+    const long F0_298631336 = 2446, F0_390180644 = 3196, F0_541196100 = 4433, F0_765366865 = 6270, F0_899976223 = 7373, F1_175875602 = 9633,
+               F1_501321110 = 12299, F1_847759065 = 15137, F1_961570560 = 16069, F2_053119869 = 16819, F2_562915447 = 20995, F3_072711026 = 25172;
+    /* even part */
+    long z1 = (in[2] + in[6]) * F0_541196100;
+    const long e2 = z1 - in[6] * F1_847759065, e3 = z1 + in[2] * F0_765366865;
+    const long e0 = (in[0] + in[4]) * 8192, e1 = (in[0] - in[4]) * 8192;
+    const long t10 = e0 + e3, t13 = e0 - e3, t11 = e1 + e2, t12 = e1 - e2;
+    /* odd part */
+    long o0 = in[7], o1 = in[5], o2 = in[3], o3 = in[1];
+    z1 = o0 + o3;
+    long z2 = o1 + o2, z3 = o0 + o2, z4 = o1 + o3;
+    const long z5 = (z3 + z4) * F1_175875602;
+    o0 *= F0_298631336; o1 *= F2_053119869; o2 *= F3_072711026; o3 *= F1_501321110;
+    z1 *= -F0_899976223; z2 *= -F2_562915447; z3 *= -F1_961570560; z4 *= -F0_390180644;
+    z3 += z5; z4 += z5;
+    o0 += z1 + z3; o1 += z2 + z4; o2 += z2 + z3; o3 += z1 + z4;
+    out[0] = t10 + o3; out[7] = t10 - o3;
+    out[1] = t11 + o2; out[6] = t11 - o2;
+    out[2] = t12 + o1; out[5] = t12 - o1;
+    out[3] = t13 + o0; out[4] = t13 - o0;
+}
 inline void idct_block(const int coef[64], uint8_t* out, int stride) {
-    static double C[8][8];
-    static bool init = false;
-    if (!init) {
-        for (int x = 0; x < 8; ++x)
-            for (int u = 0; u < 8; ++u) C[x][u] = (u == 0 ? std::sqrt(0.5) : 1.0) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0) * 0.5;
-        init = true;
+    long ws[64];
+    for (int x = 0; x < 8; ++x) { /* pass 1: columns, results keep 2 fractional bits */
+        long in[8], o[8];
+        for (int v = 0; v < 8; ++v) in[v] = coef[v * 8 + x];
+        idct_1d(in, o);
+        for (int v = 0; v < 8; ++v) ws[v * 8 + x] = descale(o[v], 13 - 2);
     }
-    double tmp[64];
-    for (int v = 0; v < 8; ++v)
+    for (int y = 0; y < 8; ++y) { /* pass 2: rows, remove the 2 bits and the factor 8 of the 2-D transform, level shift, clamp */
+        long o[8];
+        idct_1d(ws + y * 8, o);
         for (int x = 0; x < 8; ++x) {
-            double s = 0;
-            for (int u = 0; u < 8; ++u) s += C[x][u] * coef[v * 8 + u];
-            tmp[v * 8 + x] = s;
-        }
-    for (int y = 0; y < 8; ++y)
-        for (int x = 0; x < 8; ++x) {
-            double s = 0;
-            for (int v = 0; v < 8; ++v) s += C[y][v] * tmp[v * 8 + x];
-            long r = std::lround(s + 128.0);
+            const int r = descale(o[x], 13 + 2 + 3) + 128;
             out[y * stride + x] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
         }
+    }
 }
 
 inline uint16_t be16(const uint8_t* p) { return (uint16_t)((p[0] << 8) | p[1]); }
@@ -271,7 +293,11 @@ inline void decode_jpeg(const uint8_t* data, size_t size, uint32_t& width, uint3
         const int sx = x * c.h / hmax, sy = y * c.v / vmax;
         return (int)c.plane[(size_t)sy * c.bw * 8 + sx];
     };
-    auto clamp8 = [](double v) { long r = std::lround(v); return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r)); };
+    /* JFIF YCbCr -> RGB (ITU-R BT.601, full range) in 16-bit fixed point with one rounding per channel, as the IJG decoders do:
+     * R = Y + 1.402 Cr, G = Y - 0.34414 Cb - 0.71414 Cr, B = Y + 1.772 Cb */
+    auto fix = [](double x) { return (long)(x * 65536.0 + 0.5); };
+    const long K_CR_R = fix(1.40200), K_CB_B = fix(1.77200), K_CR_G = fix(0.71414), K_CB_G = fix(0.34414), HALF = 1L << 15;
+    auto clamp8 = [](long r) { return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r)); };
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
             uint8_t* o = rgb.data() + ((size_t)y * W + x) * 3;
@@ -280,10 +306,10 @@ inline void decode_jpeg(const uint8_t* data, size_t size, uint32_t& width, uint3
             } else if (adobe_rgb) {
                 o[0] = (uint8_t)sample(comps[0], x, y); o[1] = (uint8_t)sample(comps[1], x, y); o[2] = (uint8_t)sample(comps[2], x, y);
             } else { /* JFIF: ITU-R BT.601 full range */
-                const double Y = sample(comps[0], x, y), cb = sample(comps[1], x, y) - 128.0, cr = sample(comps[2], x, y) - 128.0;
-                o[0] = clamp8(Y + 1.402 * cr);
-                o[1] = clamp8(Y - 0.344136286 * cb - 0.714136286 * cr);
-                o[2] = clamp8(Y + 1.772 * cb);
+                const long Y = sample(comps[0], x, y), cb = sample(comps[1], x, y) - 128, cr = sample(comps[2], x, y) - 128;
+                o[0] = clamp8(Y + ((K_CR_R * cr + HALF) >> 16));
+                o[1] = clamp8(Y + ((-K_CB_G * cb + HALF - K_CR_G * cr) >> 16));
+                o[2] = clamp8(Y + ((K_CB_B * cb + HALF) >> 16));
             }
         }
 }
