@@ -36,7 +36,7 @@ SIMDS_PER_CU = 4
 MX_CYCLES_PER_WAVE_TILE = 4 * 32 + 64 * 2
 MX_CYCLES_PER_WAVE_SEGMENT = 3 * 2
 PROFILE_TAGS = {("balls1080p", 1): "r02_mx", ("balls1080p", 0): "r02_valu", ("stress10000", 1): "r02_stress10k", ("stress10000", 0): "r02_stress10k_valu",
-                ("textured", 0): "r02_textured"}
+                ("textured", 5): "r02_textured"}
 
 
 def profile_traffic(tag, kernel):
@@ -65,28 +65,13 @@ def profile_valu_rate(tag):
     path = os.path.join(ROOT, "profiles", f"{tag}_sq_pmc.txt")
     if not os.path.exists(path):
         return None
+    import re
+
     for line in open(path):
-        if "VALU wave-instructions per SIMD-cycle" in line:
-            try:
-                return float(line.split(":")[-1].split()[0])
-            except ValueError:
-                return None
+        m = re.search(r"VALU wave-instructions per SIMD-cycle = ([0-9.]+)", line)
+        if m:
+            return float(m.group(1))
     return None
-
-
-def build_workload(name, width, spp, depth):
-    from raytracer_amd import presets
-
-    if name == "balls1080p":
-        return presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(width, spp, depth), "bouncing_balls(seed=1)"
-    if name == "mars":
-        return presets.mars_texture_scene(), presets.default_camera(width, spp, depth), "mars_texture_scene"
-    if name == "textured":
-        return presets.textured_scene(), presets.textured_camera(width, spp, depth), "textured_scene"
-    if name.startswith("stress"):
-        n = int(name[6:] or 10000)
-        return presets.stress_scene(n, 1), presets.stress_camera(width, spp, depth), f"stress({n})"
-    raise SystemExit(f"unknown workload {name}")
 
 
 def cpu_baseline_c1(seed):
@@ -405,8 +390,8 @@ def main():
         # rank 0's kernel: per-GPU rate.  With frames in flight the launches share the chip (each one's event time spans
         # its neighbours' too), so the rate is priced with this rank's share of the wall time instead: a lower bound.
         achieved = (flops / ((kern_ms if depth == 1 else elapsed * 1e3) * 1e-3)) / 1e12 if kern_ms > 0 else 0.0
-        tiny = scene.flat.n_spheres <= 8 and kind == 0
-        kernel_name = ["render_kernel_f32_tiny" if tiny else "render_kernel_f32", "render_kernel_f32_mx", "render_kernel_f32_bvh(_lds)", "render_kernel_f64<2>", "render_kernel_f64_mx"][kind]
+        tiny = kind == 5
+        kernel_name = ["render_kernel_f32", "render_kernel_f32_mx", "render_kernel_f32_bvh(_lds)", "render_kernel_f64<2>", "render_kernel_f64_mx", "render_kernel_f32_tiny"][kind]
         n_launch = max(1, len(stats))
         ms_avg = kern_ms / n_launch
         t_priced = (kern_ms if depth == 1 else elapsed * 1e3) * 1e-3  # s; with frames in flight the launches overlap: wall time, a lower bound
@@ -478,7 +463,8 @@ def main():
                 "closest_hit": ["brute-force LDS tile loop, broad phase on the vector ALU",
                                 "brute-force LDS tile loop, broad-phase dot products on the matrix pipe (split-f16 MFMA), exact narrow phase on the vector ALU",
                                 "bounding-ball tree (MIRT_FLAG_BVH)", "brute-force tile loop, f64",
-                                "brute-force tile loop, f64: f32 broad phase on the matrix pipe, exact f64 narrow phase and shading"][kind],
+                                "brute-force tile loop, f64: f32 broad phase on the matrix pipe, exact f64 narrow phase and shading",
+                                "exact test on every sphere, no broad phase (scenes of a handful of spheres)"][kind],
             },
             "roofline": roof,
             "multi_gpu": None if per_rank is None else {

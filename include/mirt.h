@@ -269,7 +269,8 @@ uint32_t mirt_part_rows(uint32_t height, uint32_t strip_rows, uint32_t part_inde
 /* Which closest-hit front end a render / primary-hits call with these arguments runs (no reference counterpart; for
  * benchmarks and tests): 0 = brute force with the broad phase on the vector ALU, 1 = brute force with the broad phase
  * on the matrix pipe, 2 = bounding-volume tree, 3 = f64 brute force on the vector ALU, 4 = f64 brute force with the (f32)
- * broad phase on the matrix pipe; negative = MIRT_ERR_* for invalid arguments. */
+ * broad phase on the matrix pipe, 5 = f32, a handful of spheres (<= 8 slots): the exact test on every sphere, no broad phase
+ * (render_kernel_f32_tiny); negative = MIRT_ERR_* for invalid arguments. */
 int mirt_closest_hit_kind(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts);
 
 /* ---- one host thread, N GPUs of one node (SURVEY.md 8b "one host thread drives N devices", 8e) ---------------------

@@ -507,7 +507,7 @@ class Camera:
         k = abi.load().mirt_closest_hit_kind(ds.handle, C.byref(self.pod), C.byref(o))
         if k < 0:
             abi.check(k)
-        return ("valu", "matrix", "bvh", "f64", "f64-matrix")[k]
+        return ("valu", "matrix", "bvh", "f64", "f64-matrix", "tiny")[k]
 
     def render(self, scene: Scene, out=None) -> None:
         """Camera::render: PPM P3 on stdout - "P3\\nW H\\n255\\n" then one "r g b\\n" line per pixel

@@ -38,6 +38,7 @@ struct MxBall { double M[3]; double rho; bool real; };
 struct mirt_scene {
     int device = 0;
     uint32_t n = 0, n_static = 0;           /* padded counts (multiples of MIRT_GROUP) seen by the kernels */
+    uint32_t n_live = 0;                    /* n before the padding to whole 32-sphere tiles */
     uint32_t true_n = 0, true_static = 0;   /* real sphere counts, for the statistics */
     uint32_t n_materials = 0;
     SceneBuffers<float> f32;
@@ -399,7 +400,7 @@ static int mx_ensure(const mirt_scene* s, const mirt_scene::MxSet& set, int e) {
 template <class R> static DevScene<R> dev_scene(const mirt_scene* s, const SceneBuffers<R>& b) {
     DevScene<R> d;
     d.A = b.A; d.B = b.B; d.orig_id = s->orig_id; d.material = s->material; d.mats = b.mats;
-    d.texels = s->texels; d.n = s->n; d.n_static = s->n_static;
+    d.texels = s->texels; d.n = s->n; d.n_static = s->n_static; d.n_live = s->n_live;
     d.S = sizeof(R) == 4 ? s->S : nullptr;
     d.n_materials = s->n_materials;
     d.bvh = s->bvh; d.bvh_S = s->bvh_S; d.bvh_idx = s->bvh_idx; d.bvh_root = s->bvh_root;
@@ -556,7 +557,7 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
                          void* d_accum = nullptr) {
     /* closest-hit front end: 0 = brute force, VALU broad phase; 1 = tree in HBM/L2; 2 = tree, records and spheres resident in
      * LDS; 3 = brute force, broad phase on the matrix pipe; 4 = f32, a handful of spheres (render_kernel_f32_tiny) */
-    const int bvh = mx ? 3 : !use_bvh ? ((sizeof(R) == 4 && s->n <= MIRT_TINY_SCENE) ? 4 : 0) /* 4 = the f32 kernel for a handful of spheres */
+    const int bvh = mx ? 3 : !use_bvh ? ((sizeof(R) == 4 && s->n_live <= MIRT_TINY_SCENE) ? 4 : 0) /* 4 = the f32 kernel for a handful of spheres */
                     : (s->bvh_n_nodes <= MIRT_BVH_LDS_NODES && s->bvh_n_recs <= MIRT_LDS_RECORDS && s->n <= MIRT_LDS_RECORDS &&
                        s->bvh_depth <= MIRT_BVH_LDS_STACK && s->n_materials <= 0x10000u && s->bvh_root != MIRT_BVH_NONE) ? 2 : 1;
     const uint32_t block = (sizeof(R) == 4 && bvh != 1) ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;
@@ -709,6 +710,7 @@ int mirt_closest_hit_kind(const mirt_scene* s, const mirt_camera* cam, const mir
     int e = 0;
     const bool mx = use_mx(s, cam, o, &e);
     if (o->precision == MIRT_F64) return mx ? 4 : 3;
+    if (!mx && s->n_live <= MIRT_TINY_SCENE) return 5;
     return mx ? 1 : 0;
 }
 void mirt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
@@ -760,6 +762,8 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
     /* ... and the whole array to whole 32-sphere tiles of the matrix-pipe broad phase (a multiple of the 16-record groups
      * of trace_cons and of MIRT_GROUP): a lane whose operands say "every record of this tile is a candidate" (origin out of
      * range, NaN) then meets a dummy record in every slot up to the end of the last tile, in HBM and in the LDS copies */
+    while (order.size() % MIRT_GROUP) order.push_back(0xFFFFFFFFu);
+    s->n_live = (uint32_t)order.size();
     while (order.size() % 32u) order.push_back(0xFFFFFFFFu);
     s->n = (uint32_t)order.size();
     s->true_n = d->n_spheres;

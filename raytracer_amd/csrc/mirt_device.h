@@ -139,6 +139,8 @@ template <class R> struct DevScene {
     const float4* S;
     unsigned long long* dbg;         /* diagnostic builds: counter of broad-phase misses (must stay 0) */
     uint32_t n, n_static;
+    uint32_t n_live;                 /* slots before the padding to whole 32-sphere tiles (statics and movings each padded to MIRT_GROUP): what
+                                        the exact-test-on-every-sphere paths of tiny scenes walk and the host's kernel choice looks at */
     uint32_t n_materials;
     /* bounding-volume tree (f32 only): nodes, the bounding records in leaf order, leaf slot -> sorted sphere index */
     const BvhNode* bvh;

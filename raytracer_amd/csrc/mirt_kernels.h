@@ -951,13 +951,13 @@ struct TracerF64 {
     const DevScene<double>& sc;
     WaveLds<double>& lds;
     __device__ inline void closest(uint32_t lane, bool active, const RayT<double>& ray, double tmin, Closest<double>& best, uint32_t& nc, PhaseTimer& pt) {
-        if (sc.n <= MIRT_TINY_SCENE) { /* a handful of spheres: the exact test on each (see TracerF32::closest) */
+        if (sc.n_live <= MIRT_TINY_SCENE) { /* a handful of spheres: the exact test on each (see TracerF32::closest) */
             best.t = (double)INFINITY;
             best.idx = 0xFFFFFFFFu;
             const double a = ray_a(ray.d);
             if (active) {
-                for (uint32_t i = 0; i < sc.n; ++i) narrow_test(sc, GeomGlobal<double>{sc}, i, ray, a, tmin, best); /* dummy records never hit */
-                nc += sc.n;
+                for (uint32_t i = 0; i < sc.n_live; ++i) narrow_test(sc, GeomGlobal<double>{sc}, i, ray, a, tmin, best); /* dummy records never hit */
+                nc += sc.n_live;
             }
             pt.stamp(PH_NARROW);
             return;
@@ -975,15 +975,15 @@ template <bool RES> struct TracerF32 {
     F32Lds& L;
     uint32_t w;
     __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
-        if (RES && sc.n <= MIRT_TINY_SCENE) {
+        if (RES && sc.n_live <= MIRT_TINY_SCENE) {
             /* a handful of spheres (the textured presets have 1-3): the exact test on each of them, no lists, no broad
              * phase - 16 bounding records per group would be mostly padding */
             best.t = INFINITY;
             best.idx = 0xFFFFFFFFu;
             const float a = ray_a(ray.d);
             if (active) {
-                for (uint32_t i = 0; i < sc.n; ++i) narrow_test(sc, GeomLds{L}, i, ray, a, tmin, best); /* dummy records never hit */
-                nc += sc.n;
+                for (uint32_t i = 0; i < sc.n_live; ++i) narrow_test(sc, GeomLds{L}, i, ray, a, tmin, best); /* dummy records never hit */
+                nc += sc.n_live;
             }
             pt.stamp(PH_NARROW);
             return;
@@ -1580,7 +1580,7 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel_f64(DevSc
     TracerF64 tr{sc, lds_all[w]};
     /* measured: the LDS copy pays where an iteration is short (a handful of spheres: textured 4K f64 17.98 -> 17.56 ms), not in
      * the all-f64 loop over hundreds of spheres (115.3 -> 116.2 ms: the compiler keeps the copy in VGPRs there) */
-    if (sc.n <= MIRT_TINY_SCENE) render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane, att);
+    if (sc.n_live <= MIRT_TINY_SCENE) render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane, att);
     else render_body(tr, sc, cam, part, rp, partial, stats, lane, att);
 }
 /* parity mode with the broad phase on the matrix pipe: f32 filter, exact f64 narrow phase and shading */

@@ -28,7 +28,7 @@ def bits(a):
 
 def _maps(oracle, sc, cam, expect="matrix", check_oracle=True):
     assert cam.closest_hit_kind(sc, precision=abi.F32) == expect
-    assert cam.closest_hit_kind(sc, precision=abi.F32, accel="valu") == "valu"
+    assert cam.closest_hit_kind(sc, precision=abi.F32, accel="valu") in ("valu", "tiny")  # tiny: <= 8 slots, exact test on every sphere
     ids, t = cam.primary_hits(sc, precision=abi.F32)
     v_ids, v_t = cam.primary_hits(sc, precision=abi.F32, accel="valu")
     assert np.array_equal(ids, v_ids) and np.array_equal(bits(t), bits(v_t))
@@ -189,7 +189,12 @@ def test_tiny_scenes_default_to_the_vector_alu(monkeypatch):
     from raytracer_amd import api
 
     monkeypatch.setattr(api, "DEFAULT_FLAGS", 0)
-    assert presets.default_camera(64, 0, 5).closest_hit_kind(presets.mars_texture_scene(), precision=abi.F32) == "valu"
+    # 1-3 spheres: no broad phase at all (render_kernel_f32_tiny) - the kind is reported so that a change of the slot padding
+    # cannot silently send these scenes through the 16-record groups of the general kernel again (it did, for one r02 build)
+    assert presets.default_camera(64, 0, 5).closest_hit_kind(presets.mars_texture_scene(), precision=abi.F32) == "tiny"
+    assert presets.textured_camera(64, 1, 5).closest_hit_kind(presets.textured_scene(), precision=abi.F32) == "tiny"
+    sc9 = presets.stress_scene(9, 1)
+    assert presets.stress_camera(64, 0, 5).closest_hit_kind(sc9, precision=abi.F32) == "valu"
     assert presets.bouncing_balls_camera(64, 0, 5).closest_hit_kind(presets.bouncing_balls_scene(1), precision=abi.F32) == "matrix"
 
 
