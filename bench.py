@@ -74,6 +74,21 @@ def profile_valu_rate(tag):
     return None
 
 
+def build_workload(name, width, spp, depth):
+    from raytracer_amd import presets
+
+    if name == "balls1080p":
+        return presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(width, spp, depth), "bouncing_balls(seed=1)"
+    if name == "mars":
+        return presets.mars_texture_scene(), presets.default_camera(width, spp, depth), "mars_texture_scene"
+    if name == "textured":
+        return presets.textured_scene(), presets.textured_camera(width, spp, depth), "textured_scene"
+    if name.startswith("stress"):
+        n = int(name[6:] or 10000)
+        return presets.stress_scene(n, 1), presets.stress_camera(width, spp, depth), f"stress({n})"
+    raise SystemExit(f"unknown workload {name}")
+
+
 def cpu_baseline_c1(seed):
     """BASELINE.json configs[0], the reference's own default render (main.rs:30-56,126-127): mars_texture_scene, 400 x 225,
     100 spp, depth 50, lens 0.4 deg - the WHOLE frame on one thread (the reference is single-threaded), f64 oracle with the

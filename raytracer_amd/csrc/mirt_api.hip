@@ -1158,7 +1158,7 @@ int mirt_measure_fma_peak(int device, double* tflops) {
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
-    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, iters = 4096, reps = 5;
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256, iters = 4096, reps = 40; /* ~25 ms: the sustained clock, not a cold burst */
     const int blocks = cus * 8; /* 256 threads = one wave per SIMD; 8 blocks per CU */
     float* out = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -68,3 +68,24 @@ def test_band_bookkeeping_roundtrip(H, S, n):
         bands[r, : len(rows)] = frame[rows]
     assert (seen == 1).all()
     assert np.array_equal(dist.deinterleave_host(bands, H, S), frame)
+
+
+def test_bench_helpers_import_and_parse_the_committed_profiles():
+    """bench.py is only ever run on the GPU box; its host-side helpers are exercised here so that an edit cannot lose one of
+    them unnoticed (it did once: a NameError surfaced only on the box)."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for name in ("build_workload", "cpu_baseline", "cpu_baseline_c1", "profile_traffic", "profile_valu_rate", "run_node", "main"):
+        assert callable(getattr(b, name)), name
+    sc, cam, label = b.build_workload("stress16", 64, 1, 2)
+    assert sc.flat.n_spheres == 16 and cam.width == 64 and label == "stress(16)"
+    t = b.profile_traffic("r02_mx", "render_kernel_f32_mx")
+    assert t and t["file"] == "profiles/r02_mx_hbm_traffic.txt" and 7.0e8 < t["bytes"] < 9.5e8 and t["write"] > 20 * t["fetch"]
+    r = b.profile_valu_rate("r02_textured")
+    assert r and 0.2 < r < 0.5
+    assert b.MX_CYCLES_PER_WAVE_TILE == 256
