@@ -206,3 +206,16 @@ def test_image_depends_on_arguments_only(monkeypatch):
     bad = cam.opts(precision=abi.F32)
     bad._reserved[0] = 7
     assert abi.load().mirt_closest_hit_kind(sc.device_scene(0).handle, C.byref(cam.pod), C.byref(bad)) == -1
+
+
+def test_fuzz_bit_exact_radiance():
+    """A slice of tools/fuzz_exact.py (run over 2 000 scenes, profiles/r02_microbench.txt): random scenes, cameras, depths, sample
+    counts and work-item sizes; f64 (both front ends) and f32 (three front ends) bit-equal to the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_exact.py"), "5000", "12"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
