@@ -339,3 +339,54 @@ def test_f32_map_differs_from_f64_only_at_a_few_edge_pixels(oracle, golden_dir):
     for name in ("mars", "balls"):
         a, b = g[f"{name}_400_f64_id"], g[f"{name}_400_f32_id"]
         assert (a != b).mean() < 2e-3
+
+
+def _np_scene(sc):
+    """The flattened scene as oracle_np wants it (plain tuples), from the same mirt_scene_desc the C++ oracle reads."""
+    f = sc.flat
+    imgs = f._img_arrays
+    texs = []
+    for t in f.tex[: f.desc.n_textures]:
+        if t.kind == abi.TEX_SOLID:
+            texs.append(("solid", tuple(t.color)))
+        elif t.kind == abi.TEX_CHECKER:
+            texs.append(("checker", t.inv_scale, tuple(t.color), tuple(t.odd)))
+        else:
+            texs.append(("image", imgs[t.image] if imgs[t.image].ndim == 3 else None))
+    mats = []
+    for m in f.mat[: f.desc.n_materials]:
+        if m.kind == abi.MAT_LAMBERTIAN:
+            mats.append(("lambertian", texs[m.texture], m.reflectance))
+        elif m.kind == abi.MAT_METAL:
+            mats.append(("metal", tuple(m.albedo), m.fuzz if m.has_fuzz else None))
+        else:
+            mats.append(("dielectric", m.ior))
+    return [(tuple(s.center0), tuple(s.center1), bool(s.moving), s.radius, mats[s.material]) for s in f.sph[: f.n_spheres]]
+
+
+def _np_cam(c):
+    return dict(lookfrom=tuple(c.lookfrom), px_du=tuple(c.px_du), px_dv=tuple(c.px_dv), vp_upper_left=tuple(c.vp_upper_left), px00_loc=tuple(c.px00_loc),
+                disk_u_r=tuple(c.disk_u_r), disk_v_r=tuple(c.disk_v_r), defocus_angle=c.defocus_angle, W=c.img_width, H=c.img_height,
+                spp=c.samples_per_pixel, depth=c.max_bounce_depth)
+
+
+@pytest.mark.parametrize("name,width,spp,depth", [("balls", 24, 3, 12), ("balls", 20, 0, 6), ("mars", 24, 4, 8), ("textured", 20, 3, 10), ("scene", 20, 3, 10)])
+def test_independent_python_render_equals_the_cpp_oracle(oracle, name, width, spp, depth):
+    """The whole stochastic path - Philox and its dimension layout, camera ray with lens and shutter time, moving spheres, the three
+    materials with their draw orders and quirks, the three textures, the recursion's product order, the sample sum, the quantiser -
+    restated a second time in plain Python floats (oracle/oracle_np.py, written from the Rust source and the RNG contract):
+    linear radiance, bytes and segment count bit-equal to oracle.cpp's f64 render (BVH walk and brute force)."""
+    sc, cam = {
+        "balls": lambda: (presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(width, spp, depth)),
+        "mars": lambda: (presets.mars_texture_scene(), presets.default_camera(width, spp, depth)),
+        "textured": lambda: (presets.textured_scene(), presets.textured_camera(width, spp, depth)),
+        "scene": lambda: (presets.scene(), presets.plain_camera(width, spp, depth)),
+    }[name]()
+    lin, q8, seg = oracle_np.render(_np_scene(sc), _np_cam(cam.pod), seed=5)
+    for use_bvh in (True, False):
+        o_lin, o_rgb8, o_seg, nan = oracle.render(sc.flat, cam.pod, abi.F64, seed=5, use_bvh=use_bvh, threads=2)
+        assert nan == 0 and o_seg == seg
+        assert np.array_equal(np.asarray(lin, np.float64).view(np.uint64), o_lin.view(np.uint64))
+        assert np.array_equal(np.asarray(q8, np.uint8), o_rgb8)
+    for k, (ctr, key) in enumerate([((0, 0, 0, 0), (0, 0)), ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2), ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0))]):
+        assert list(oracle_np.philox4x32_10(ctr, key)) == oracle.philox(ctr, key)
