@@ -129,6 +129,7 @@ pub struct mirt_stats {
 }
 
 pub const MIRT_NODE_MAX_DEVICES: usize = 16;
+pub const MIRT_NODE_SHARED_DEVICES: u32 = 1; // mirt_node_create flag, test rigs only
 pub const MIRT_GATHER_TO_ROOT: u32 = 0;
 pub const MIRT_GATHER_ALLGATHER: u32 = 1;
 
@@ -169,7 +170,7 @@ const _: () = assert!(std::mem::size_of::<mirt_stats>() == 72);
 extern "C" {
     pub fn mirt_abi_version() -> c_int;
     pub fn mirt_measure_fma_peak(device: c_int, tflops: *mut f64) -> c_int;
-    pub fn mirt_node_create(desc: *const mirt_scene_desc, device_ids: *const c_int, n_devices: u32, out: *mut *mut mirt_node) -> c_int;
+    pub fn mirt_node_create(desc: *const mirt_scene_desc, device_ids: *const c_int, n_devices: u32, flags: u32, out: *mut *mut mirt_node) -> c_int;
     pub fn mirt_node_destroy(node: *mut mirt_node);
     pub fn mirt_node_device_count(node: *const mirt_node) -> u32;
     pub fn mirt_node_render(node: *mut mirt_node, cam: *const mirt_camera, opts: *const mirt_opts, gather: u32, rgb_linear: *mut c_void, rgb8: *mut u8, stats: *mut mirt_node_stats) -> c_int;

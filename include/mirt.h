@@ -297,7 +297,11 @@ typedef struct mirt_node_stats {
     uint64_t band_segments[MIRT_NODE_MAX_DEVICES];
 } mirt_node_stats;
 typedef struct mirt_node mirt_node;
-int mirt_node_create(const mirt_scene_desc* desc, const int* device_ids, uint32_t n_devices, mirt_node** out);
+/* flags: 0, or MIRT_NODE_SHARED_DEVICES to let several ranks name the same GPU.  RCCL itself refuses that (one rank per
+ * GPU), so the flag is only good with an exchange library that copes: tests/stub_rccl, which lets the N-rank partition,
+ * exchange and scatter logic of this file be rehearsed on a one-GPU box. */
+#define MIRT_NODE_SHARED_DEVICES 1u
+int mirt_node_create(const mirt_scene_desc* desc, const int* device_ids, uint32_t n_devices, uint32_t flags, mirt_node** out);
 void mirt_node_destroy(mirt_node* node);
 uint32_t mirt_node_device_count(const mirt_node* node);
 /* Host buffers, full frames (rgb_linear: W*H*3 reals, rgb8: W*H*3 bytes; either may be NULL, not both).  When only rgb8 is

@@ -109,6 +109,7 @@ class MirtStats(C.Structure):
 
 
 NODE_MAX_DEVICES = 16
+NODE_SHARED_DEVICES = 1  # mirt_node_create flag (test rigs only)
 GATHER_TO_ROOT, GATHER_ALLGATHER = 0, 1  # mirt_gather_kind: grouped ncclSend/ncclRecv to the root | ncclAllGather
 
 
@@ -210,7 +211,7 @@ def load():
     lib.mirt_render_wait.restype = C.c_int
     lib.mirt_closest_hit_kind.argtypes = [vp, P(MirtCamera), P(MirtOpts)]
     lib.mirt_closest_hit_kind.restype = C.c_int
-    lib.mirt_node_create.argtypes = [P(MirtSceneDesc), P(C.c_int), u32, P(vp)]
+    lib.mirt_node_create.argtypes = [P(MirtSceneDesc), P(C.c_int), u32, u32, P(vp)]
     lib.mirt_node_destroy.argtypes = [vp]
     lib.mirt_node_destroy.restype = None
     lib.mirt_node_device_count.argtypes = [vp]

@@ -291,12 +291,13 @@ class DeviceScene:
 class NodeScene:
     """Owns a mirt_node: one scene replica, stream and band buffer per GPU of `devices`; the root is devices[0]."""
 
-    def __init__(self, flat: FlatScene, devices: Sequence[int]):
+    def __init__(self, flat: FlatScene, devices: Sequence[int], shared_devices: bool = False):
         self.flat = flat
         self.devices = list(devices)
         self.handle = C.c_void_p()
         ids = (C.c_int * len(self.devices))(*self.devices)
-        abi.check(abi.load().mirt_node_create(C.byref(flat.desc), ids, len(self.devices), C.byref(self.handle)))
+        flags = abi.NODE_SHARED_DEVICES if shared_devices else 0  # only with tests/stub_rccl: RCCL wants one rank per GPU
+        abi.check(abi.load().mirt_node_create(C.byref(flat.desc), ids, len(self.devices), flags, C.byref(self.handle)))
 
     def close(self):
         if self.handle:

@@ -118,15 +118,17 @@ static int grow(void** buf, size_t* have, size_t need) {
 
 extern "C" {
 
-int mirt_node_create(const mirt_scene_desc* desc, const int* device_ids, uint32_t n_devices, mirt_node** out) {
+int mirt_node_create(const mirt_scene_desc* desc, const int* device_ids, uint32_t n_devices, uint32_t flags, mirt_node** out) {
     if (!desc || !out || !device_ids) return nfail(MIRT_ERR_INVALID, "null argument");
     *out = nullptr;
+    if (flags & ~(uint32_t)MIRT_NODE_SHARED_DEVICES) return nfail(MIRT_ERR_INVALID, "unknown mirt_node_create flag");
     if (n_devices == 0 || n_devices > MIRT_NODE_MAX_DEVICES) return nfail(MIRT_ERR_INVALID, "n_devices must be 1.." + std::to_string(MIRT_NODE_MAX_DEVICES));
     const int ndev = mirt_device_count();
     for (uint32_t i = 0; i < n_devices; ++i) {
         if (device_ids[i] < 0 || device_ids[i] >= ndev) return nfail(MIRT_ERR_NO_DEVICE, "device id " + std::to_string(device_ids[i]) + " out of range");
         for (uint32_t j = 0; j < i; ++j)
-            if (device_ids[j] == device_ids[i]) return nfail(MIRT_ERR_INVALID, "device ids must be distinct (RCCL needs one rank per GPU)");
+            if (device_ids[j] == device_ids[i] && !(flags & MIRT_NODE_SHARED_DEVICES))
+                return nfail(MIRT_ERR_INVALID, "device ids must be distinct (RCCL needs one rank per GPU)");
     }
     mirt_node* n = new (std::nothrow) mirt_node();
     if (!n) return nfail(MIRT_ERR_NOMEM, "out of host memory");

@@ -1,6 +1,6 @@
 """mirt_node_* - one host thread, N GPUs inside libmirt.so, RCCL exchange - on the GPUs this box has (the
-round's box has ONE: RCCL then runs with a communicator of one rank; the band bookkeeping for N > 1 is covered by the
-partition tests of test_gpu_parity.py and the gloo test of test_dist.py).  Needs a GPU."""
+round's box has ONE: RCCL then runs with a communicator of one rank; N = 2..8 ranks are rehearsed on that one GPU through
+tests/stub_rccl, see the last test).  Needs a GPU."""
 import ctypes as C
 
 import numpy as np
@@ -63,6 +63,23 @@ def test_node_argument_errors(node_and_scene):
     assert lib.mirt_node_render(node.handle, C.byref(cam.pod), C.byref(o), abi.GATHER_TO_ROOT, None, None, None) == -1
     h = C.c_void_p()
     ids = (C.c_int * 2)(0, 0)
-    assert lib.mirt_node_create(C.byref(sc.flat.desc), ids, 2, C.byref(h)) == -1 and b"distinct" in lib.mirt_last_error()
+    assert lib.mirt_node_create(C.byref(sc.flat.desc), ids, 2, 0, C.byref(h)) == -1 and b"distinct" in lib.mirt_last_error()
     ids = (C.c_int * 1)(99)
-    assert lib.mirt_node_create(C.byref(sc.flat.desc), ids, 1, C.byref(h)) == -2
+    assert lib.mirt_node_create(C.byref(sc.flat.desc), ids, 1, 0, C.byref(h)) == -2
+
+
+def test_node_n_ranks_on_one_gpu_through_the_stub():
+    """N = 2, 3, 5, 8 ranks of mirt_node on ONE GPU: MIRT_NODE_SHARED_DEVICES plus tests/stub_rccl (HIP copies behind RCCL's
+    entry points).  Covers what a one-GPU box otherwise cannot: the exchange slots and offsets, the send-to-root and
+    all-gather call patterns, the scatter of N bands and the per-rank statistics.  Runs in a child process without torch
+    (torch holds the real librccl.so.1)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = os.path.join(root, "tests", "stub_rccl")
+    assert os.path.exists(os.path.join(stub, "librccl.so.1")), "tests/stub_rccl/librccl.so.1 missing: run __graft_entry__.build()"
+    env = dict(os.environ, PYTHONPATH=root, LD_LIBRARY_PATH=stub + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([sys.executable, "-u", os.path.join(stub, "node_ranks.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "STUB_NODE_OK 32" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
