@@ -30,10 +30,11 @@ FP64_VALU_PEAK_TFLOPS = 78.6
 NOMINAL_CLOCK_GHZ = 2.4  # the clock both nominal peaks are quoted at; under this load the chip runs at ~2.0 GHz (profiles/*_sq_pmc.txt)
 SIMDS_PER_CU = 4
 # Issue slots of the matrix-pipe broad phase that no schedule can avoid: per wave and tile of 32 spheres
-# 4 x v_mfma_f32_32x32x16_f16 (8 passes = 32 cycles each) and, per (ray, sphere) pair, one v_fma_f32 and one v_alignbit_b32
-# (64 wave-instructions of 2 cycles); the matrix core and the vector ALU of a SIMD do not run side by side
-# (bench/mfma_overlap.hip), so the cycles add.  Per segment, the `5` of SURVEY 8d (a = D.D) is 3 more instructions.
-MX_CYCLES_PER_WAVE_TILE = 4 * 32 + 64 * 2
+# 4 x v_mfma_f32_32x32x16_f16 (8 passes = 32 cycles each: the whole quadratic form of the conservative test, K = 32 over
+# two chained MFMAs) and, per (ray, sphere) pair, the one v_alignbit_b32 that collects its sign (32 wave-instructions of
+# 2 cycles); priced additively (bench/mfma_coexec.hip: ~4.5 VALU per MFMA hide in its shadow, so this is the conservative
+# figure).  Per segment, the `5` of SURVEY 8d (a = D.D) is 3 more instructions.
+MX_CYCLES_PER_WAVE_TILE = 4 * 32 + 32 * 2
 MX_CYCLES_PER_WAVE_SEGMENT = 3 * 2
 PROFILE_TAGS = {("balls1080p", 1): "r02_mx", ("balls1080p", 0): "r02_valu", ("stress10000", 1): "r02_stress10k", ("stress10000", 0): "r02_stress10k_valu",
                 ("textured", 5): "r02_textured"}
@@ -439,9 +440,9 @@ def main():
                          "issue_cycles_per_wave_and_segment": cyc, "sphere_tiles": tiles, "clock_ghz": NOMINAL_CLOCK_GHZ, "simds": cus * SIMDS_PER_CU,
                          "bound_ms_per_launch": round(t_bound / n_launch * 1e3, 3),
                          "vs_fp32_valu_peak": round(achieved / FP32_VALU_PEAK_TFLOPS, 4)})
-            note += (f"; bound = mandatory issue slots of the matrix-pipe broad phase: per wave and segment {tiles} tiles x (4 MFMA x 32 + 64 VALU x 2 cycles) + 6 = {cyc} SIMD-cycles, "
+            note += (f"; bound = mandatory issue slots of the matrix-pipe broad phase: per wave and segment {tiles} tiles x (4 MFMA x 32 + 32 VALU x 2 cycles) + 6 = {cyc} SIMD-cycles, "
                      f"segments / 64 waves, {cus * SIMDS_PER_CU} SIMDs at the nominal {NOMINAL_CLOCK_GHZ} GHz; `peak` is that bound expressed in the same algorithmic flops, so frac = bound time / kernel time; "
-                     "`vs_fp32_valu_peak` is the algorithmic rate against the vector-ALU peak alone, which this kernel can exceed because 7 of the 9 VALU operations per pair moved to the "
+                     "`vs_fp32_valu_peak` is the algorithmic rate against the vector-ALU peak alone, which this kernel can exceed because 8 of the 9 VALU operations per pair moved to the "
                      "matrix pipe - the metric's '% of FP32 VALU peak' is `valu_broad.frac` (render_kernel_f32, every pair on the vector ALU)")
         elif kind == 2:
             roof.update({"bound": "latency (tree walk; no brute-force flops)", "achieved": None, "peak": None, "unit": "TFLOP/s", "frac": None})

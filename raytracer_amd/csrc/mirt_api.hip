@@ -297,9 +297,11 @@ static int upload_real(mirt_scene* s, const mirt_scene_desc* d, const std::vecto
 }
 
 /* ---- matrix-pipe broad phase (trace_mx): split-f16 sphere operands -----------------------------------------
- * Per tile of 32 sorted spheres 64 x 16 B: lane l carries K half (l / 32) of the sphere in MFMA row (l % 32); row i
- * holds sorted sphere 32 T + 16 ((i / 4) % 2) + (i % 4) + 4 (i / 8), so that the 16 rows a result lane receives are 16
- * consecutive spheres.  Values are in the scene scale 2^e with max (|M| + rho) 2^e <= 64. */
+ * Per tile of 32 sorted spheres 2 x 64 x 16 B, [tile][MFMA m][lane]: lane l carries K half (l / 32) of MFMA m for the
+ * sphere in row (l % 32); row i holds sorted sphere 32 T + 16 ((i / 4) % 2) + (i % 4) + 4 (i / 8), so that the 16 rows a
+ * result lane receives are 16 consecutive spheres.  The 32 K slots are listed in trace_mx (mirt_kernels.h): the six
+ * products M_i M_j, the three M_i, 1 and w, each but the 1 as an f16 pair (hi, lo).  Values are in the scene scale 2^e
+ * with max (|M| + rho) 2^e <= 64. */
 static uint16_t f16_bits(_Float16 h) { uint16_t b; memcpy(&b, &h, 2); return b; }
 static _Float16 f16_from_bits(uint16_t b) { _Float16 h; memcpy(&h, &b, 2); return h; }
 static _Float16 f16_round_down(double x) { /* the largest f16 <= x (finite range) */
@@ -361,32 +363,36 @@ static int mx_ensure(const mirt_scene* s, const mirt_scene::MxSet& set, int e) {
     const double sc = std::ldexp(1.0, e);
     const double eps = 1.0 / 16777216.0, F = 1.0 / 2097152.0; /* 2^-24, 2^-21 */
     const size_t ntiles = (balls.size() + 31) / 32;
-    std::vector<uint4> SM((ntiles + 1) * 64); /* + one tile: the streaming loop prefetches one ahead */
+    std::vector<uint4> SM((ntiles + 1) * 128); /* + one tile: the streaming loop prefetches one ahead */
+    auto split = [](double x, _Float16& h, _Float16& l) {
+        h = (_Float16)x;
+        l = (_Float16)(x - (double)h);
+    };
     for (size_t T = 0; T < ntiles; ++T)
-        for (uint32_t l = 0; l < 64; ++l) {
-            const uint32_t i = l % 32, sub = (i / 4) % 2, r = (i % 4) + 4 * (i / 8);
+        for (uint32_t row = 0; row < 32; ++row) {
+            const uint32_t sub = (row / 4) % 2, r = (row % 4) + 4 * (row / 8);
             const size_t idx = 32 * T + 16 * sub + r;
-            _Float16 mh[3] = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f}, ml[3] = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-            _Float16 wh = (_Float16)60000.0f, wl = (_Float16)0.f; /* dummy: q <= |O|^2 - 60000 < 0 for every admissible ray */
+            _Float16 sv[32];
+            for (int k = 0; k < 32; ++k) sv[k] = (_Float16)0.f;
+            sv[27] = sv[28] = sv[29] = (_Float16)1.0f;
+            sv[30] = (_Float16)60000.0f; /* dummy: q = c0 - 60000 < 0 for every admissible ray (c0 <= 0) */
             if (idx < balls.size() && balls[idx].real) {
                 const MxBall& b = balls[idx];
-                double M2 = 0;
-                for (int a = 0; a < 3; ++a) {
-                    const double m = b.M[a] * sc; /* exact: power of two */
-                    mh[a] = (_Float16)m;
-                    ml[a] = (_Float16)(m - (double)mh[a]);
-                    M2 += m * m;
+                const double m[3] = {b.M[0] * sc, b.M[1] * sc, b.M[2] * sc}; /* exact: power of two */
+                const double M2 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2];
+                static const int pi[6] = {0, 1, 2, 0, 0, 1}, pj[6] = {0, 1, 2, 1, 2, 2}; /* xx yy zz xy xz yz */
+                for (int k = 0; k < 9; ++k) {
+                    _Float16 h, l;
+                    split(k < 6 ? m[pi[k]] * m[pj[k]] : m[k - 6], h, l);
+                    sv[3 * k] = h; sv[3 * k + 1] = l; sv[3 * k + 2] = h; /* against the ray's (hi, hi, lo) */
                 }
                 const double rho = b.rho * sc, Ml = std::sqrt(M2);
                 const double w = M2 - rho * rho - (double)MIRT_MX_MARGIN_TEST * (256.0 * eps * (M2 + rho * rho) + F * Ml);
-                wh = (_Float16)w;
-                wl = f16_round_down(w - (double)wh); /* wh + wl <= w */
+                sv[30] = (_Float16)w;
+                sv[31] = f16_round_down(w - (double)sv[30]); /* wh + wl <= w */
             }
-            _Float16 v[8];
-            const _Float16 one = (_Float16)1.0f;
-            if (l < 32) { v[0] = mh[0]; v[1] = ml[0]; v[2] = mh[0]; v[3] = ml[0]; v[4] = mh[1]; v[5] = ml[1]; v[6] = mh[1]; v[7] = ml[1]; }
-            else        { v[0] = mh[2]; v[1] = ml[2]; v[2] = mh[2]; v[3] = ml[2]; v[4] = one;   v[5] = one;   v[6] = wh;    v[7] = wl; }
-            memcpy(&SM[T * 64 + l], v, 16);
+            for (uint32_t m = 0; m < 2; ++m)
+                for (uint32_t half = 0; half < 2; ++half) memcpy(&SM[(T * 2 + m) * 64 + half * 32 + row], &sv[m * 16 + half * 8], 16);
         }
     uint4* dev = nullptr;
     HIP_TRY(hipMalloc((void**)&dev, SM.size() * sizeof(uint4)));
@@ -536,7 +542,7 @@ static int occupancy_of(const void* fn, int block) {
 
 /* the two render kernels behind one name */
 static const void* render_fn(double, int bvh) { return bvh == 3 ? (const void*)render_kernel_f64_mx : (const void*)render_kernel_f64<2>; }
-static const void* render_fn(float, int bvh) { return bvh == 4 ? (const void*)render_kernel_f32_tiny : bvh == 3 ? (const void*)render_kernel_f32_mx : bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
+static const void* render_fn(float, int bvh) { return bvh == 4 ? (const void*)render_kernel_f32_tiny : bvh == 5 ? (const void*)render_kernel_f32_mx<MxLdsSmall> : bvh == 3 ? (const void*)render_kernel_f32_mx<MxLds> : bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
 static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam,
                                  const DevPart& part, const RenderParams& rp, double* partial, DevStats* stats, double* att) {
     if (bvh == 3) hipLaunchKernelGGL(render_kernel_f64_mx, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats, att);
@@ -545,7 +551,8 @@ static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStre
 static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<float>& sc, const DevCamera<float>& cam,
                                  const DevPart& part, const RenderParams& rp, float* partial, DevStats* stats, float*) {
     if (bvh == 4) hipLaunchKernelGGL(render_kernel_f32_tiny, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
-    else if (bvh == 3) hipLaunchKernelGGL(render_kernel_f32_mx, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    else if (bvh == 5) hipLaunchKernelGGL(render_kernel_f32_mx<MxLdsSmall>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    else if (bvh == 3) hipLaunchKernelGGL(render_kernel_f32_mx<MxLds>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh == 2) hipLaunchKernelGGL(render_kernel_f32_bvh_lds, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh) hipLaunchKernelGGL(render_kernel_f32_bvh, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else hipLaunchKernelGGL(render_kernel_f32, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
@@ -556,8 +563,9 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
                          void* d_lin, uint8_t* d_rgb8, hipStream_t st, bool use_bvh, bool mx, uint32_t first_sample = 0, uint32_t sample_count = 0xFFFFFFFFu,
                          void* d_accum = nullptr) {
     /* closest-hit front end: 0 = brute force, VALU broad phase; 1 = tree in HBM/L2; 2 = tree, records and spheres resident in
-     * LDS; 3 = brute force, broad phase on the matrix pipe; 4 = f32, a handful of spheres (render_kernel_f32_tiny) */
-    const int bvh = mx ? 3 : !use_bvh ? ((sizeof(R) == 4 && s->n_live <= MIRT_TINY_SCENE) ? 4 : 0) /* 4 = the f32 kernel for a handful of spheres */
+     * LDS; 3 = brute force, broad phase on the matrix pipe; 4 = f32, a handful of spheres (render_kernel_f32_tiny);
+     * 5 = 3 with the LDS layout for scenes of up to MIRT_MX_SMALL_RECORDS sorted slots (f32) */
+    const int bvh = mx ? ((sizeof(R) == 4 && s->n <= MIRT_MX_SMALL_RECORDS) ? 5 : 3) : !use_bvh ? ((sizeof(R) == 4 && s->n_live <= MIRT_TINY_SCENE) ? 4 : 0) /* 4 = the f32 kernel for a handful of spheres */
                     : (s->bvh_n_nodes <= MIRT_BVH_LDS_NODES && s->bvh_n_recs <= MIRT_LDS_RECORDS && s->n <= MIRT_LDS_RECORDS &&
                        s->bvh_depth <= MIRT_BVH_LDS_STACK && s->n_materials <= 0x10000u && s->bvh_root != MIRT_BVH_NONE) ? 2 : 1;
     const uint32_t block = (sizeof(R) == 4 && bvh != 1) ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;

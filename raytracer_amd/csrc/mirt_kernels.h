@@ -493,25 +493,27 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
 #endif
 #define MIRT_MX_SHRINK (1.0f - 2.0e-5f * (float)MIRT_MX_MARGIN_TEST) /* <= 1 - 335 * 2^-24 */
 #define MIRT_MX_FLOOR_LIN (5.2e-7f * (float)MIRT_MX_MARGIN_TEST) /* >= 2^-20.9 */
-#define MIRT_MX_FLOOR_ABS (6.0e-8f * (float)MIRT_MX_MARGIN_TEST) /* >= 2^-24 */
+#define MIRT_MX_FLOOR_ABS (1.6e-7f * (float)MIRT_MX_MARGIN_TEST) /* >= 5.1 x 2^-25 */
 typedef _Float16 mirt_h8 __attribute__((ext_vector_type(8)));
 typedef float mirt_f16v __attribute__((ext_vector_type(16)));
 typedef uint32_t mirt_u4 __attribute__((ext_vector_type(4)));
-#define MIRT_MX_LDS_MATS 640u
-struct MxLds {
+/* Two layouts of the 160 KB: scenes of up to 512 sorted slots (the bench scene) keep 640 material records beside their
+ * operands; up to 1024 slots the operands take twice the room and the materials get what is left. */
+template <uint32_t RECORDS, uint32_t MATS> struct MxLdsT {
     static constexpr bool GEOM_LDS = true; /* exact records and material ids of a resident scene are here as well */
-    uint4 SM[MIRT_LDS_RECORDS * 2]; /* 64 x 16 B per tile of 32 spheres */
-    float4 A[MIRT_LDS_RECORDS];
-    float4 B[MIRT_LDS_RECORDS];
-    uint16_t mat[MIRT_LDS_RECORDS];
+    static constexpr uint32_t N_RECORDS = RECORDS, N_MATS = MATS;
+    uint4 SM[RECORDS * 4]; /* 2 x 64 x 16 B per tile of 32 spheres */
+    float4 A[RECORDS];
+    float4 B[RECORDS];
+    uint16_t mat[RECORDS];
     static constexpr uint32_t LDS_ENT_CAP = 12; /* in 4-byte words: trace_mx stores 6 tile entries of 8 bytes */
     uint32_t ent[MIRT_F32_WAVES][LDS_ENT_CAP][MIRT_WAVE];
-    DevMaterial<float> mats[MIRT_MX_LDS_MATS]; /* the scene's materials when they fit: the shading of a segment starts with this record */
+    DevMaterial<float> mats[MATS]; /* the scene's materials when they fit: the shading of a segment starts with this record */
     uint32_t params[120]; /* the block's copy of camera, partition and launch parameters (render_kernel_f32_mx) */
     /* all threads of the block; true when the scene is resident (larger scenes read their operands through L1/L2) */
     __device__ inline bool fill(const DevScene<float>& sc) {
-        const bool res = sc.n <= MIRT_LDS_RECORDS && sc.n_materials <= 0x10000u;
-        if (sc.n_materials <= MIRT_MX_LDS_MATS) {
+        const bool res = sc.n <= RECORDS && sc.n_materials <= 0x10000u;
+        if (sc.n_materials <= MATS) {
             const uint32_t nd = sc.n_materials * (uint32_t)(sizeof(DevMaterial<float>) / 4);
             const uint32_t* src = (const uint32_t*)sc.mats;
             uint32_t* dst = (uint32_t*)mats;
@@ -519,7 +521,7 @@ struct MxLds {
         }
         if (res) {
             const uint32_t ntiles = (sc.n + 31) / 32;
-            for (uint32_t i = threadIdx.x; i < ntiles * 64; i += blockDim.x) SM[i] = sc.SM[i];
+            for (uint32_t i = threadIdx.x; i < ntiles * 128; i += blockDim.x) SM[i] = sc.SM[i];
             for (uint32_t i = threadIdx.x; i < sc.n; i += blockDim.x) {
                 A[i] = sc.A[i];
                 B[i] = sc.B[i];
@@ -530,17 +532,22 @@ struct MxLds {
         return res;
     }
 };
+#define MIRT_MX_SMALL_RECORDS 512u
+typedef MxLdsT<MIRT_MX_SMALL_RECORDS, 640u> MxLdsSmall; /* 32 + 8 + 8 + 1 + 48 + 45 KB */
+typedef MxLdsT<MIRT_LDS_RECORDS, 184u> MxLds;            /* 64 + 16 + 16 + 2 + 48 + 12.9 KB */
+static_assert(sizeof(MxLds) <= 160u * 1024u && sizeof(MxLdsSmall) <= 160u * 1024u, "MxLds layouts must fit the CU's LDS");
 /* f64 kernels (256-thread blocks): only the operands and the entry lists; the exact f64 records come through L2 */
+#define MIRT_MX64_RECORDS 512u /* three blocks per CU: 32 KB of operands + 12 KB of entry lists each */
 struct MxLds64 {
     static constexpr bool GEOM_LDS = false;
     static constexpr uint32_t LDS_ENT_CAP = MIRT_ENT_CAP;
-    uint4 SM[MIRT_LDS_RECORDS * 2];
+    uint4 SM[MIRT_MX64_RECORDS * 4];
     uint32_t ent[MIRT_WAVES_PER_BLOCK][MIRT_ENT_CAP][MIRT_WAVE];
     __device__ inline bool fill(const DevScene<double>& sc) {
-        const bool res = sc.n <= MIRT_LDS_RECORDS;
+        const bool res = sc.n <= MIRT_MX64_RECORDS;
         if (res) {
             const uint32_t ntiles = (sc.n + 31) / 32;
-            for (uint32_t i = threadIdx.x; i < ntiles * 64; i += blockDim.x) SM[i] = sc.SM[i];
+            for (uint32_t i = threadIdx.x; i < ntiles * 128; i += blockDim.x) SM[i] = sc.SM[i];
         }
         __syncthreads();
         return res;
@@ -571,7 +578,7 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
     const uint32_t ntiles = (sc.n + 31) / 32;
     uint2(*ent2)[MIRT_WAVE] = reinterpret_cast<uint2(*)[MIRT_WAVE]>(L.ent[w]); /* one entry per tile: both 16-sphere halves */
     /* ---- the ray's operands ---- */
-    mirt_h8 bgx, bgy, bex, bey;
+    mirt_h8 bx0, bx1, by0, by1;
     {
         const R inv = filter_rsq(a_true);
         const V3<float> Dn = {(float)(ray.d.x * inv), (float)(ray.d.y * inv), (float)(ray.d.z * inv)};
@@ -580,34 +587,50 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
         const float o2 = __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x));
         const float k2 = o2 * MIRT_MX_SHRINK - __builtin_fmaf(MIRT_MX_FLOOR_LIN, filter_sqrt(o2), MIRT_MX_FLOOR_ABS);
         const bool ok = o2 <= MIRT_MX_K2MAX; /* false for NaN */
-        _Float16 dhx, dlx, dhy, dly, dhz, dlz, k1h, k1l, ohx, olx, ohy, oly, ohz, olz, k2h, k2l;
-        mx_split(Dn.x, dhx, dlx); mx_split(Dn.y, dhy, dly); mx_split(Dn.z, dhz, dlz); mx_split(-k1, k1h, k1l);
-        mx_split(2.0f * O.x, ohx, olx); mx_split(2.0f * O.y, ohy, oly); mx_split(2.0f * O.z, ohz, olz); mx_split(-k2, k2h, k2l);
-        const _Float16 z = (_Float16)0.0f, m1 = (_Float16)-1.0f;
+        /* the nine coefficients and the constant of q as a polynomial in the sphere's M */
+        const float dx2 = Dn.x + Dn.x, dy2 = Dn.y + Dn.y, m2k1 = -(k1 + k1);
+        float cf[10] = {Dn.x * Dn.x, Dn.y * Dn.y, Dn.z * Dn.z, dx2 * Dn.y, dx2 * Dn.z, dy2 * Dn.z,
+                        __builtin_fmaf(m2k1, Dn.x, O.x + O.x), __builtin_fmaf(m2k1, Dn.y, O.y + O.y), __builtin_fmaf(m2k1, Dn.z, O.z + O.z),
+                        __builtin_fmaf(k1, k1, -k2)};
         if (!active || !ok) {
-            /* the two special lanes are decided by their operands, not by masks in the tile loop: with Dn = O = 0 the test
-             * reads q = -k2 - w, and |w| <= 64^2 for a real record (60000 for a dummy).  No ray: -k2 = -60000, q < 0 for
-             * every record, never a candidate.  Origin out of range (or NaN): -k2 = +60000, q >= 0 for every record, all
+            /* the two special lanes are decided by their operands, not by masks in the tile loop: with every coefficient 0 the
+             * test reads q = c0 - w, and |w| <= 64^2 for a real record (60000 for a dummy).  No ray: c0 = -60000, q < 0 for
+             * every record, never a candidate.  Origin out of range (or NaN): c0 = +60000, q >= 0 for every record, all
              * of them candidates (a dummy too: the exact test rejects it). */
-            dhx = dlx = dhy = dly = dhz = dlz = k1h = k1l = z;
-            ohx = olx = ohy = oly = ohz = olz = k2l = z;
-            k2h = active ? (_Float16)60000.0f : (_Float16)-60000.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) cf[k] = 0.0f;
+            cf[9] = active ? 60000.0f : -60000.0f;
         }
-        const mirt_h8 glo = {dhx, dhx, dlx, dlx, dhy, dhy, dly, dly}, ghi = {dhz, dhz, dlz, dlz, k1h, k1l, z, z};
-        const mirt_h8 elo = {ohx, ohx, olx, olx, ohy, ohy, oly, oly}, ehi = {ohz, ohz, olz, olz, k2h, k2l, m1, m1};
-        /* X operand: lanes 0-31 their own low half, lanes 32-63 the high half of ray (lane - 32);
+        _Float16 rv[32];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            _Float16 h, l;
+            mx_split(cf[k], h, l);
+            rv[3 * k] = h; rv[3 * k + 1] = h; rv[3 * k + 2] = l; /* against the sphere's (hi, lo, hi) */
+        }
+        {
+            _Float16 h, m, l;
+            mx_split(cf[9], h, m);
+            l = (_Float16)((cf[9] - (float)h) - (float)m); /* both differences are exact in f32 */
+            rv[27] = h; rv[28] = m; rv[29] = l;
+            rv[30] = rv[31] = (_Float16)-1.0f;
+        }
+        /* K halves of this lane's own ray for the two chained MFMAs.
+         * X operand: lanes 0-31 their own low half, lanes 32-63 the high half of ray (lane - 32);
          * Y operand: lanes 0-31 the low half of ray (lane + 32), lanes 32-63 their own high half */
-        mirt_u4 gx = __builtin_bit_cast(mirt_u4, glo), gy = __builtin_bit_cast(mirt_u4, ghi);
-        mirt_u4 ex = __builtin_bit_cast(mirt_u4, elo), ey = __builtin_bit_cast(mirt_u4, ehi);
+        const mirt_h8 lo0 = {rv[0], rv[1], rv[2], rv[3], rv[4], rv[5], rv[6], rv[7]}, hi0 = {rv[8], rv[9], rv[10], rv[11], rv[12], rv[13], rv[14], rv[15]};
+        const mirt_h8 lo1 = {rv[16], rv[17], rv[18], rv[19], rv[20], rv[21], rv[22], rv[23]}, hi1 = {rv[24], rv[25], rv[26], rv[27], rv[28], rv[29], rv[30], rv[31]};
+        mirt_u4 x0 = __builtin_bit_cast(mirt_u4, lo0), y0 = __builtin_bit_cast(mirt_u4, hi0);
+        mirt_u4 x1 = __builtin_bit_cast(mirt_u4, lo1), y1 = __builtin_bit_cast(mirt_u4, hi1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            auto sg = __builtin_amdgcn_permlane32_swap(gx[k], gy[k], false, false);
-            gx[k] = sg[0]; gy[k] = sg[1];
-            auto se = __builtin_amdgcn_permlane32_swap(ex[k], ey[k], false, false);
-            ex[k] = se[0]; ey[k] = se[1];
+            auto s0 = __builtin_amdgcn_permlane32_swap(x0[k], y0[k], false, false);
+            x0[k] = s0[0]; y0[k] = s0[1];
+            auto s1 = __builtin_amdgcn_permlane32_swap(x1[k], y1[k], false, false);
+            x1[k] = s1[0]; y1[k] = s1[1];
         }
-        bgx = __builtin_bit_cast(mirt_h8, gx); bgy = __builtin_bit_cast(mirt_h8, gy);
-        bex = __builtin_bit_cast(mirt_h8, ex); bey = __builtin_bit_cast(mirt_h8, ey);
+        bx0 = __builtin_bit_cast(mirt_h8, x0); by0 = __builtin_bit_cast(mirt_h8, y0);
+        bx1 = __builtin_bit_cast(mirt_h8, x1); by1 = __builtin_bit_cast(mirt_h8, y1);
     }
     /* sphere operands: the block-resident LDS copy, or (big scenes) straight from L1/L2 - every wave of the chip reads the
      * same 1 KB per tile, one coalesced 16-byte load per lane, the next tile's already on its way while this one is tested
@@ -615,8 +638,8 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
     const mirt_h8* SM = RES ? (const mirt_h8*)L.SM : (const mirt_h8*)sc.SM;
     const uint32_t sub = lane >> 5;
     uint32_t t = 0;
-    mirt_h8 pre = {};
-    if (!RES) pre = SM[lane];
+    mirt_h8 pre0 = {}, pre1 = {};
+    if (!RES) { pre0 = SM[lane]; pre1 = SM[64 + lane]; }
     while (t < ntiles) { /* one pass unless some lane's entry list fills up */
         uint32_t cnt = 0;
         const uint32_t gbase = 2 * t;
@@ -624,27 +647,26 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
         tlimit = tlimit < ntiles ? tlimit : ntiles;
         bool flush = false;
         for (; t < tlimit && !flush; ++t) {
-            mirt_h8 a;
+            mirt_h8 a0, a1;
             if (RES) {
-                a = SM[t * 64 + lane];
+                a0 = SM[t * 128 + lane];
+                a1 = SM[t * 128 + 64 + lane];
             } else {
-                a = pre;
-                pre = SM[(t + 1) * 64 + lane];
+                a0 = pre0; a1 = pre1;
+                pre0 = SM[(t + 1) * 128 + lane];
+                pre1 = SM[(t + 1) * 128 + 64 + lane];
             }
             const mirt_f16v zero = {};
             uint32_t mx = 2 * t - gbase + sub, my = mx;
-            {
-                const mirt_f16v h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bgx, zero, 0, 0, 0);
-                const mirt_f16v e = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bex, zero, 0, 0, 0);
+            /* q for 32 rays x 32 spheres per chain of two: all that is left to the vector ALU is collecting the signs */
+            mirt_f16v qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bx0, zero, 0, 0, 0);
+            mirt_f16v qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, by0, zero, 0, 0, 0);
+            qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bx1, qx, 0, 0, 0);
+            qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, by1, qy, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = __builtin_amdgcn_alignbit(mx, __float_as_uint(__builtin_fmaf(h[r], h[r], e[r])), 31);
-            }
-            {
-                const mirt_f16v h = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bgy, zero, 0, 0, 0);
-                const mirt_f16v e = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bey, zero, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) mx = __builtin_amdgcn_alignbit(mx, __float_as_uint(qx[r]), 31);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) my = __builtin_amdgcn_alignbit(my, __float_as_uint(__builtin_fmaf(h[r], h[r], e[r])), 31);
-            }
+            for (int r = 0; r < 16; ++r) my = __builtin_amdgcn_alignbit(my, __float_as_uint(qy[r]), 31);
             /* lanes 0-31 hold (ray l, rows of sub 0) and (ray l + 32, sub 0); lanes 32-63 (ray l - 32, sub 1) and (ray l, sub 1) */
             auto sw = __builtin_amdgcn_permlane32_swap(mx, my, false, false);
             mx = sw[0]; /* this lane's ray, spheres 32 t .. 32 t + 15 */
@@ -998,31 +1020,31 @@ template <bool RES> struct TracerF32 {
     __device__ inline const DevMaterial<float>& material_record(uint32_t idx) const { return sc.mats[material(idx)]; }
 };
 
-template <bool RES> struct TracerF32Mx {
+template <bool RES, class LDS = MxLds> struct TracerF32Mx {
     typedef float Real;
     static constexpr bool RESUMABLE = false;
     const DevScene<float>& sc;
-    MxLds& L;
+    LDS& L;
     uint32_t w;
     __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
         const unsigned long long live = __ballot(active);
         if ((uint32_t)__popcll(live) <= MIRT_FEW_LANES) {
-            if (RES) trace_few(sc, GeomLdsT<MxLds>{L}, lane, live, ray, tmin, best, nc);
+            if (RES) trace_few(sc, GeomLdsT<LDS>{L}, lane, live, ray, tmin, best, nc);
             else trace_few(sc, GeomGlobal<float>{sc}, lane, live, ray, tmin, best, nc);
             pt.stamp(PH_NARROW);
         } else {
-            trace_mx<float, MxLds, RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
+            trace_mx<float, LDS, RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
         }
     }
     __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const {
-        if (RES) return make_hit(sc, GeomLdsT<MxLds>{L}, c, ray);
+        if (RES) return make_hit(sc, GeomLdsT<LDS>{L}, c, ray);
         return make_hit(sc, GeomGlobal<float>{sc}, c, ray);
     }
     __device__ inline uint32_t material(uint32_t idx) const { return RES ? (uint32_t)L.mat[idx] : sc.material[idx]; }
     /* by value: the record may come from the LDS copy or from HBM/L2 (two address spaces) */
     __device__ inline DevMaterial<float> material_record(uint32_t idx) const {
         const uint32_t m = material(idx);
-        if (sc.n_materials <= MIRT_MX_LDS_MATS) return L.mats[m];
+        if (sc.n_materials <= LDS::N_MATS) return L.mats[m];
         return sc.mats[m];
     }
 };
@@ -1649,21 +1671,23 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
     render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane);
 }
 
-/* the same with the broad phase on the matrix pipe (scenes whose coordinates fit the split-f16 operands) */
+/* the same with the broad phase on the matrix pipe (scenes whose coordinates fit the split-f16 operands); LDS = MxLdsSmall
+ * for scenes of up to MIRT_MX_SMALL_RECORDS sorted slots (chosen by the host), MxLds otherwise */
+template <class LDS>
 __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32_mx(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
                                                                        float* __restrict__ partial, DevStats* __restrict__ stats) {
-    __shared__ MxLds L;
-    /* the LDS of this kernel is full: the parameter copy (stage_params) has its place inside MxLds */
+    __shared__ LDS L;
+    /* the LDS of this kernel is full: the parameter copy (stage_params) has its place inside the layout */
     static_assert(sizeof(LaunchParams<float>) <= sizeof(L.params), "MxLds::params too small");
     LaunchParams<float>* P = reinterpret_cast<LaunchParams<float>*>(L.params);
     stage_params(P, cam, part, rp);
     const bool res = L.fill(sc); /* ends with the block barrier */
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     if (res) {
-        TracerF32Mx<true> tr{sc, L, w};
+        TracerF32Mx<true, LDS> tr{sc, L, w};
         render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
     } else {
-        TracerF32Mx<false> tr{sc, L, w};
+        TracerF32Mx<false, LDS> tr{sc, L, w};
         render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
     }
 }
