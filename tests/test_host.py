@@ -88,4 +88,4 @@ def test_bench_helpers_import_and_parse_the_committed_profiles():
     assert t and t["file"] == "profiles/r02_mx_hbm_traffic.txt" and 7.0e8 < t["bytes"] < 9.5e8 and t["write"] > 20 * t["fetch"]
     r = b.profile_valu_rate("r02_textured")
     assert r and 0.2 < r < 0.5
-    assert b.MX_CYCLES_PER_WAVE_TILE == 256
+    assert b.MX_CYCLES_PER_WAVE_TILE == 192
