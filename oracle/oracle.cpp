@@ -19,7 +19,7 @@
  * keyed on (seed; pixel, sample, bounce, block) - see DESIGN.md "RNG contract".
  *
  * Two instantiations: Real = double (the reference's arithmetic) and Real = float (the build's
- * throughput mode; same operation sequence in binary32 except the fused discriminant, see disc()).
+ * throughput mode; same operation sequence in binary32 except the discriminant, see Disc<float>).
  */
 #include "../include/mirt.h"
 
@@ -165,7 +165,9 @@ template <class R> static inline V3<R> cvt3(const double* p) { return {(R)p[0], 
 
 /* The discriminant of sphere.rs:81-90.
  *   double: the reference's sequence, unfused.
- *   float : the build's f32 spec - same algebra, products fused (fmaf) exactly as the HIP kernel does. */
+ *   float : the build's f32 spec - the same quantity through the perpendicular from the centre to the line,
+ *           d = a (r^2 - |oc - (h/a) D|^2) with h/a = h * (1/a): the textbook form cancels catastrophically in
+ *           binary32 once |oc| >> r; products fused (fmaf) exactly as the HIP kernel does. */
 template <class R> struct Disc;
 template <> struct Disc<double> {
     static inline double a_of(V3<double> d) { return dot(d, d); } /* sphere.rs:87 */
@@ -187,8 +189,9 @@ template <> struct Disc<float> {
     }
     static inline void hd(const Sphere<float>& s, V3<float> oc, V3<float> d, float a, float& h, float& disc) {
         h = std::fmaf(d.z, oc.z, std::fmaf(d.y, oc.y, d.x * oc.x));
-        float c = std::fmaf(oc.x, oc.x, std::fmaf(oc.y, oc.y, std::fmaf(oc.z, oc.z, -s.r2)));
-        disc = std::fmaf(h, h, -(a * c));
+        const float q = h * (1.0f / a);
+        const float lx = std::fmaf(-q, d.x, oc.x), ly = std::fmaf(-q, d.y, oc.y), lz = std::fmaf(-q, d.z, oc.z);
+        disc = a * (s.r2 - std::fmaf(lz, lz, std::fmaf(ly, ly, lx * lx)));
     }
 };
 

@@ -27,23 +27,38 @@
 
 namespace mirt {
 
-/* ---- discriminant of sphere.rs:83-90 ------------------------------------------------------------- */
-__device__ inline double ray_a(V3<double> d) { return dot(d, d); }
-__device__ inline float ray_a(V3<float> d) { return __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x)); }
+/* ---- discriminant of sphere.rs:83-90 -------------------------------------------------------------
+ * double: the reference's expressions, one IEEE operation at a time (d = h*h - a*c with c = |oc|^2 - r^2).
+ * float (the f32 spec of the throughput kernels): the same quantity through the perpendicular from the centre to the
+ * line, d = a (r^2 - |oc - (h/a) D|^2).  The textbook form subtracts two numbers of size |oc|^2 to get one of size r^2:
+ * in binary32, for a sphere of radius 0.1 seen from 100 units away, that leaves d with an error of ~5 % of r^2, roots off
+ * by up to ~0.03, hit points well inside the sphere - and scattered rays that hit the same sphere again from within (the
+ * 10 000-sphere stress frame traced 60 % more segments than in binary64, and darker spheres).  The perpendicular form has
+ * no such cancellation (Haines, Guenther, Akenine-Moeller, "Precision improvements for ray/sphere intersection", Ray
+ * Tracing Gems ch. 7); h / a is taken as h * (1 / a) with one correctly rounded division per ray. */
+template <class R> struct RayA;
+template <> struct RayA<double> { double a; };
+template <> struct RayA<float> { float a, inv; };
+__device__ inline RayA<double> ray_a(V3<double> d) { return {dot(d, d)}; }
+__device__ inline RayA<float> ray_a(V3<float> d) {
+    const float a = __builtin_fmaf(d.z, d.z, __builtin_fmaf(d.y, d.y, d.x * d.x));
+    return {a, 1.0f / a};
+}
 
-__device__ inline void disc(V3<double> oc, V3<double> D, double a, double r2, double& h, double& d, double& c) {
+__device__ inline void disc(V3<double> oc, V3<double> D, RayA<double> ra, double r2, double& h, double& d, double& c) {
     h = dot(D, oc);
     c = dot(oc, oc) - r2;
-    d = h * h - a * c;
+    d = h * h - ra.a * c;
 }
-__device__ inline void disc(V3<float> oc, V3<float> D, float a, float r2, float& h, float& d, float& c) {
+__device__ inline void disc(V3<double> oc, V3<double> D, RayA<double> ra, double r2, double& h, double& d) {
+    double c;
+    disc(oc, D, ra, r2, h, d, c);
+}
+__device__ inline void disc(V3<float> oc, V3<float> D, RayA<float> ra, float r2, float& h, float& d) {
     h = __builtin_fmaf(D.z, oc.z, __builtin_fmaf(D.y, oc.y, D.x * oc.x));
-    c = __builtin_fmaf(oc.x, oc.x, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.z, oc.z, -r2)));
-    d = __builtin_fmaf(h, h, -(a * c));
-}
-template <class R> __device__ inline void disc(V3<R> oc, V3<R> D, R a, R r2, R& h, R& d) {
-    R c;
-    disc(oc, D, a, r2, h, d, c);
+    const float q = h * ra.inv;
+    const float lx = __builtin_fmaf(-q, D.x, oc.x), ly = __builtin_fmaf(-q, D.y, oc.y), lz = __builtin_fmaf(-q, D.z, oc.z);
+    d = ra.a * (r2 - __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx)));
 }
 /* |h| below which h*h may be subnormal (the behind-the-ray shortcut of narrow_test needs h*h normal) */
 __device__ inline float h_normal_min(float) { return 1e-18f; }
@@ -100,7 +115,7 @@ enum { DG_NARROW_ROUND = 0, DG_NARROW_MOVING, DG_NARROW_ROOTS, DG_NARROW_FAR, DG
 /* exact per-candidate test: sphere.rs:91-101 against the interval (tmin, best.t), ties -> lowest hit id.  The hit
  * id of a sphere is only looked up on an exact tie in t (and once for the winner, by the caller). */
 template <class R, class G>
-__device__ inline void narrow_test(const DevScene<R>& sc, const G& geo, uint32_t i, const RayT<R>& ray, R a, R tmin, Closest<R>& best) {
+__device__ inline void narrow_test(const DevScene<R>& sc, const G& geo, uint32_t i, const RayT<R>& ray, RayA<R> ra, R tmin, Closest<R>& best) {
     typename Vec4<R>::type sa = geo.a(i);
     V3<R> C = {sa.x, sa.y, sa.z};
     if (i >= sc.n_static) {
@@ -109,13 +124,23 @@ __device__ inline void narrow_test(const DevScene<R>& sc, const G& geo, uint32_t
         C = center_at(C, V3<R>{sb.x, sb.y, sb.z}, ray.tm);
     }
     V3<R> oc = C - ray.o;
-    R h, d, c;
-    disc(oc, ray.d, a, sa.w, h, d, c);
+    const R a = ra.a;
+    R h, d;
+    /* Sphere entirely behind the ray (h < 0, origin outside): sqrt(d) <= -h, so both roots (h -+ sqrt(d))/a are <= 0 < tmin.
+     * Exact shortcuts: they reject only what the root test below would reject, before paying for the sqrt and the two
+     * divisions.  double: c > 0 gives d = rn(h*h - a*c) <= rn(h*h), and sqrt(rn(h*h)) == |h| exactly when h*h is normal.
+     * float: d <= rn(h*h) is tested as such (the f32 discriminant does not go through c). */
+    bool behind;
+    if constexpr (sizeof(R) == 8) {
+        R c;
+        disc(oc, ray.d, ra, sa.w, h, d, c);
+        behind = c > (R)0.0;
+    } else {
+        disc(oc, ray.d, ra, sa.w, h, d);
+        behind = d <= h * h;
+    }
     if (!(d >= (R)0.0)) return;
-    /* Sphere entirely behind the ray (h < 0, origin outside): d = rn(h*h - a*c) <= rn(h*h), and sqrt(rn(h*h)) == |h|
-     * exactly when h*h is normal, so sqrt(d) <= -h: both roots (h -+ sqrt(d))/a are <= 0 < tmin.  Exact shortcut: it
-     * rejects only what the root test below would reject, before paying for the sqrt and the two divisions. */
-    if (h < -h_normal_min(h) && c > (R)0.0 && tmin >= (R)0.0) return;
+    if (h < -h_normal_min(h) && behind && tmin >= (R)0.0) return;
     MIRT_DIAG(sc, DG_NARROW_ROOTS, true);
     R sq = m_sqrt(d);
     /* strict interval (utils/interval.rs:37-39); an exact tie with the current best goes to the lower hit id
@@ -177,8 +202,9 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
     best.t = (R)INFINITY;
     best.idx = 0xFFFFFFFFu;
     /* an inactive lane gets a = NaN: every d is NaN and `d >= 0` is false for free */
-    const R a_true = ray_a(ray.d);
-    const R a = active ? a_true : (R)NAN;
+    const RayA<R> a_true = ray_a(ray.d);
+    RayA<R> a = a_true;
+    if (!active) a = ray_a(V3<R>{(R)NAN, (R)NAN, (R)NAN});
     const V3<R> O = ray.o, D = ray.d;
     const R tm = ray.tm;
     const uint32_t ngroups = sc.n / MIRT_GROUP;         /* n and n_static are multiples of MIRT_GROUP */
@@ -344,8 +370,8 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
     best.t = INFINITY;
     best.idx = 0xFFFFFFFFu;
     const V3<float> O = ray.o;
-    const float a_true = ray_a(ray.d);
-    const float inv = filter_rsq(a_true);
+    const RayA<float> a_true = ray_a(ray.d);
+    const float inv = filter_rsq(a_true.a);
     const V3<float> Dn = {ray.d.x * inv, ray.d.y * inv, ray.d.z * inv};
     const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
     /* an inactive lane gets k2 = +inf: q = -inf, never a candidate */
@@ -499,14 +525,14 @@ typedef float mirt_f16v __attribute__((ext_vector_type(16)));
 typedef uint32_t mirt_u4 __attribute__((ext_vector_type(4)));
 /* Two layouts of the 160 KB: scenes of up to 512 sorted slots (the bench scene) keep 640 material records beside their
  * operands; up to 1024 slots the operands take twice the room and the materials get what is left. */
-template <uint32_t RECORDS, uint32_t MATS> struct MxLdsT {
+template <uint32_t RECORDS, uint32_t MATS, uint32_t ENT_WORDS = 12> struct MxLdsT {
     static constexpr bool GEOM_LDS = true; /* exact records and material ids of a resident scene are here as well */
     static constexpr uint32_t N_RECORDS = RECORDS, N_MATS = MATS;
     uint4 SM[RECORDS * 4]; /* 2 x 64 x 16 B per tile of 32 spheres */
     float4 A[RECORDS];
     float4 B[RECORDS];
     uint16_t mat[RECORDS];
-    static constexpr uint32_t LDS_ENT_CAP = 12; /* in 4-byte words: trace_mx stores 6 tile entries of 8 bytes */
+    static constexpr uint32_t LDS_ENT_CAP = ENT_WORDS; /* in 4-byte words: trace_mx stores ENT_WORDS / 2 tile entries of 8 bytes */
     uint32_t ent[MIRT_F32_WAVES][LDS_ENT_CAP][MIRT_WAVE];
     DevMaterial<float> mats[MATS]; /* the scene's materials when they fit: the shading of a segment starts with this record */
     uint32_t params[120]; /* the block's copy of camera, partition and launch parameters (render_kernel_f32_mx) */
@@ -533,7 +559,10 @@ template <uint32_t RECORDS, uint32_t MATS> struct MxLdsT {
     }
 };
 #define MIRT_MX_SMALL_RECORDS 512u
-typedef MxLdsT<MIRT_MX_SMALL_RECORDS, 640u> MxLdsSmall; /* 32 + 8 + 8 + 1 + 48 + 45 KB */
+#ifndef MIRT_MX_SMALL_ENT
+#define MIRT_MX_SMALL_ENT 14
+#endif
+typedef MxLdsT<MIRT_MX_SMALL_RECORDS, 640u, MIRT_MX_SMALL_ENT> MxLdsSmall; /* 32 + 8 + 8 + 1 + 56 + 45 KB; 7 entries per lane: 13.58 -> 13.53 ms against 6 */
 typedef MxLdsT<MIRT_LDS_RECORDS, 184u> MxLds;            /* 64 + 16 + 16 + 2 + 48 + 12.9 KB */
 static_assert(sizeof(MxLds) <= 160u * 1024u && sizeof(MxLdsSmall) <= 160u * 1024u, "MxLds layouts must fit the CU's LDS");
 /* f64 kernels (256-thread blocks): only the operands and the entry lists; the exact f64 records come through L2 */
@@ -574,13 +603,13 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
                                 Closest<R>& best, uint32_t& narrow_count, PhaseTimer& pt) {
     best.t = (R)INFINITY;
     best.idx = 0xFFFFFFFFu;
-    const R a_true = ray_a(ray.d);
+    const RayA<R> a_true = ray_a(ray.d);
     const uint32_t ntiles = (sc.n + 31) / 32;
     uint2(*ent2)[MIRT_WAVE] = reinterpret_cast<uint2(*)[MIRT_WAVE]>(L.ent[w]); /* one entry per tile: both 16-sphere halves */
     /* ---- the ray's operands ---- */
     mirt_h8 bx0, bx1, by0, by1;
     {
-        const R inv = filter_rsq(a_true);
+        const R inv = filter_rsq(a_true.a);
         const V3<float> Dn = {(float)(ray.d.x * inv), (float)(ray.d.y * inv), (float)(ray.d.z * inv)};
         const V3<float> O = {(float)(ray.o.x * (R)sc.mx_scale), (float)(ray.o.y * (R)sc.mx_scale), (float)(ray.o.z * (R)sc.mx_scale)};
         const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
@@ -746,7 +775,7 @@ __device__ inline void trace_few(const DevScene<R>& sc, const G& geo, uint32_t l
         live &= live - 1ull;
         auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); };
         const RayT<float> r = {{bc(ray.o.x), bc(ray.o.y), bc(ray.o.z)}, {bc(ray.d.x), bc(ray.d.y), bc(ray.d.z)}, bc(ray.tm)};
-        const float a = ray_a(r.d);
+        const RayA<float> a = ray_a(r.d);
         Closest<float> b = {INFINITY, 0xFFFFFFFFu};
         for (uint32_t i = lane; i < sc.n; i += MIRT_WAVE) narrow_test(sc, geo, i, r, a, tmin, b); /* dummy records never hit */
         /* minimum over the wave of (t, hit id): positive floats order like their bit patterns */
@@ -844,8 +873,8 @@ template <class Store>
 __device__ inline void trace_bvh_resume(const DevScene<float>& sc, const Store& store, uint32_t (*stk)[MIRT_WAVE], uint32_t lane, const RayT<float>& ray,
                                         float tmin, Closest<float>& best, BvhState& st, uint32_t keep, uint32_t& narrow_count, PhaseTimer& pt) {
     const V3<float> O = ray.o;
-    const float a_true = ray_a(ray.d);
-    const float inv = filter_rsq(a_true);
+    const RayA<float> a_true = ray_a(ray.d);
+    const float inv = filter_rsq(a_true.a);
     const V3<float> Dn = {ray.d.x * inv, ray.d.y * inv, ray.d.z * inv};
     const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
     const float o2 = __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x));
@@ -976,7 +1005,7 @@ struct TracerF64 {
         if (sc.n_live <= MIRT_TINY_SCENE) { /* a handful of spheres: the exact test on each (see TracerF32::closest) */
             best.t = (double)INFINITY;
             best.idx = 0xFFFFFFFFu;
-            const double a = ray_a(ray.d);
+            const RayA<double> a = ray_a(ray.d);
             if (active) {
                 for (uint32_t i = 0; i < sc.n_live; ++i) narrow_test(sc, GeomGlobal<double>{sc}, i, ray, a, tmin, best); /* dummy records never hit */
                 nc += sc.n_live;
@@ -1002,7 +1031,7 @@ template <bool RES> struct TracerF32 {
              * phase - 16 bounding records per group would be mostly padding */
             best.t = INFINITY;
             best.idx = 0xFFFFFFFFu;
-            const float a = ray_a(ray.d);
+            const RayA<float> a = ray_a(ray.d);
             if (active) {
                 for (uint32_t i = 0; i < sc.n_live; ++i) narrow_test(sc, GeomLds{L}, i, ray, a, tmin, best); /* dummy records never hit */
                 nc += sc.n_live;
