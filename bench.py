@@ -477,7 +477,7 @@ def main():
                 "frames_in_flight": depth,
                 "seed": args.seed,
                 "closest_hit": ["brute-force LDS tile loop, broad phase on the vector ALU",
-                                "brute-force LDS tile loop, broad-phase dot products on the matrix pipe (split-f16 MFMA), exact narrow phase on the vector ALU",
+                                "brute-force LDS tile loop, the whole broad-phase test as one split-f16 contraction on the matrix pipe (two chained MFMAs per 32 rays x 32 spheres), exact narrow phase on the vector ALU",
                                 "bounding-ball tree (MIRT_FLAG_BVH)", "brute-force tile loop, f64",
                                 "brute-force tile loop, f64: f32 broad phase on the matrix pipe, exact f64 narrow phase and shading",
                                 "exact test on every sphere, no broad phase (scenes of a handful of spheres)"][kind],

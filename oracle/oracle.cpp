@@ -107,7 +107,8 @@ template <class R> static inline V3<R> operator-(V3<R> a) { return {-a.x, -a.y, 
 /* point3.rs:48-58: scalar_prod; the `self == rhs` branch evaluates the same expression. */
 template <class R> static inline R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 template <class R> static inline R size(V3<R> a) { return std::sqrt(dot(a, a)); }                 /* :44-46 */
-template <class R> static inline V3<R> unit(V3<R> a) { return a / size(a); }                      /* :39-41 */
+static inline V3<double> unit(V3<double> a) { return a / size(a); }                               /* :39-41 */
+static inline V3<float> unit(V3<float> a) { return a * (1.0f / size(a)); } /* f32 spec: one division, three products */
 template <class R> static inline V3<R> cross(V3<R> a, V3<R> b) {                                 /* :60-68 */
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
@@ -121,7 +122,10 @@ template <class R> static inline V3<R> reflect(V3<R> v, V3<R> n) { return v - (n
 template <class R> struct Ray { /* ray.rs:3-34 */
     V3<R> o, d;
     R tm;
-    V3<R> at(R t) const { return o + d * t; } /* :27-29 */
+    V3<R> at(R t) const { /* :27-29; f32 spec: fused */
+        if constexpr (sizeof(R) == 8) return o + d * t;
+        else return {std::fmaf(d.x, t, o.x), std::fmaf(d.y, t, o.y), std::fmaf(d.z, t, o.z)};
+    }
 };
 
 template <class R> struct Interval { /* interval.rs */
@@ -214,11 +218,13 @@ template <class R> static inline bool sphere_hit(const Sphere<R>& s, uint32_t id
     Disc<R>::hd(s, oc, ray.d, a, h, d);
     if (d < (R)0.0) return false;
     R sq = std::sqrt(d);
-    R t = (h - sq) / a;
-    if (!I.surrounds(t)) t = (h + sq) / a;
+    /* f32 spec: the two roots through the ray's 1 / a, the normal through the sphere's 1 / r (products instead of divisions) */
+    const R inv_a = (R)1.0 / a;
+    R t = sizeof(R) == 8 ? (h - sq) / a : (h - sq) * inv_a;
+    if (!I.surrounds(t)) t = sizeof(R) == 8 ? (h + sq) / a : (h + sq) * inv_a;
     if (!I.surrounds(t)) return false;
     V3<R> p = ray.at(t);
-    V3<R> on = (p - C) / s.r;
+    V3<R> on = sizeof(R) == 8 ? (p - C) / s.r : (p - C) * ((R)1.0 / s.r);
     out.p = p;
     out.t = t;
     out.id = id;
@@ -446,7 +452,8 @@ template <class R> static inline V3<R> texture_color(const Scene<R>& sc, const T
         uint32_t i = std::min(as_u32(u * (R)im.w), im.w - 1);
         uint32_t j = std::min(as_u32(v * (R)im.h), im.h - 1);
         const uint8_t* px = &im.rgb[((size_t)j * im.w + i) * 3];
-        return {(R)px[0] / (R)255.0, (R)px[1] / (R)255.0, (R)px[2] / (R)255.0};
+        if constexpr (sizeof(R) == 8) return {(R)px[0] / (R)255.0, (R)px[1] / (R)255.0, (R)px[2] / (R)255.0};
+        else return {(R)px[0], (R)px[1], (R)px[2]}; /* f32 spec: bytes here, one product with (1/255)/reflectance in scatter() */
     }
     }
 }
@@ -484,7 +491,10 @@ static inline bool scatter(const Scene<R>& sc, const Material<R>& m, const Ray<R
             V3<R> dir = hr.n + random_unit_on_sphere(ub, uc, ud);
             if (near_zero(dir)) dir = hr.n;
             out = {hr.p, dir, rin.tm};
-            att = texture_color(sc, sc.texs[m.tex], hr.u, hr.v, hr.p) / m.reflectance;
+            if (sizeof(R) == 4 && sc.texs[m.tex].kind == MIRT_TEX_IMAGE && sc.imgs[sc.texs[m.tex].image].h != 0)
+                att = texture_color(sc, sc.texs[m.tex], hr.u, hr.v, hr.p) * (((R)1.0 / (R)255.0) / m.reflectance);
+            else
+                att = texture_color(sc, sc.texs[m.tex], hr.u, hr.v, hr.p) / m.reflectance;
             return true;
         }
         return false;

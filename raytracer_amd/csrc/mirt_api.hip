@@ -267,7 +267,7 @@ static int upload_real(mirt_scene* s, const mirt_scene_desc* d, const std::vecto
         A[k].x = c0[0]; A[k].y = c0[1]; A[k].z = c0[2]; A[k].w = r * r;
         if (sp.moving) { B[k].x = c1[0] - c0[0]; B[k].y = c1[1] - c0[1]; B[k].z = c1[2] - c0[2]; }
         else { B[k].x = B[k].y = B[k].z = (R)0.0; }
-        B[k].w = r;
+        B[k].w = sizeof(R) == 8 ? r : (R)1.0 / r; /* make_hit: f64 divides by r (sphere.rs:103), the f32 spec multiplies by 1 / r */
     }
     std::vector<DevMaterial<R>> mats(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; ++i) {
@@ -288,6 +288,7 @@ static int upload_real(mirt_scene* s, const mirt_scene_desc* d, const std::vecto
                 o.odd = {(R)t.odd[0] / o.reflectance, (R)t.odd[1] / o.reflectance, (R)t.odd[2] / o.reflectance};
             } else {
                 o.img_w = imgs[t.image].w; o.img_h = imgs[t.image].h; o.img_offset = imgs[t.image].offset;
+                if (sizeof(R) == 4) o.inv_scale = ((R)1.0 / (R)255.0) / o.reflectance; /* f32 spec: texel byte -> colour / reflectance in one product */
             }
         }
     }
@@ -348,7 +349,7 @@ static bool mx_pick(const mirt_scene* s, const mirt_scene::MxSet& set, const mir
         if (b.real) {
             const double Ml = std::sqrt(b.M[0] * b.M[0] + b.M[1] * b.M[1] + b.M[2] * b.M[2]) * sc, rho = b.rho * sc;
             ++real;
-            if (2.0 * Ml / 2097152.0 + 6.0e-8 > 0.5 * rho * rho) ++coarse;
+            if (2.0 * Ml / 2097152.0 + 1.6e-7 > 0.5 * rho * rho) ++coarse;
         }
     if (coarse * 4 > real) return false;
     *e_out = e;

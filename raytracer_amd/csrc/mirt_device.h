@@ -87,7 +87,9 @@ __device__ inline void lens_sincos(double u, double& s, double& c) {
     sincos(u * TAU, &s, &c); /* one range reduction for both */
 }
 
-template <class R> __device__ inline V3<R> unit(V3<R> a) { return a / m_sqrt(dot(a, a)); } /* point3.rs:39-46 */
+/* point3.rs:39-46; the f32 spec takes one division and three products instead of three divisions */
+__device__ inline V3<double> unit(V3<double> a) { return a / m_sqrt(dot(a, a)); }
+__device__ inline V3<float> unit(V3<float> a) { return a * (1.0f / m_sqrt(dot(a, a))); }
 template <class R> __device__ inline V3<R> reflect(V3<R> v, V3<R> n) { return v - (n * (R)2.0) * dot(v, n); } /* point3.rs:116-118 */
 
 /* ---- 4-wide sphere records ------------------------------------------------------------------------ */

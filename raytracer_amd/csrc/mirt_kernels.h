@@ -45,6 +45,10 @@ __device__ inline RayA<float> ray_a(V3<float> d) {
     return {a, 1.0f / a};
 }
 
+/* sphere.rs:92 / :96, (h -+ sqrt(d)) / a: the f32 spec multiplies by the ray's 1 / a */
+__device__ inline double root_over_a(double num, RayA<double> ra) { return num / ra.a; }
+__device__ inline float root_over_a(float num, RayA<float> ra) { return num * ra.inv; }
+
 __device__ inline void disc(V3<double> oc, V3<double> D, RayA<double> ra, double r2, double& h, double& d, double& c) {
     h = dot(D, oc);
     c = dot(oc, oc) - r2;
@@ -124,7 +128,6 @@ __device__ inline void narrow_test(const DevScene<R>& sc, const G& geo, uint32_t
         C = center_at(C, V3<R>{sb.x, sb.y, sb.z}, ray.tm);
     }
     V3<R> oc = C - ray.o;
-    const R a = ra.a;
     R h, d;
     /* Sphere entirely behind the ray (h < 0, origin outside): sqrt(d) <= -h, so both roots (h -+ sqrt(d))/a are <= 0 < tmin.
      * Exact shortcuts: they reject only what the root test below would reject, before paying for the sqrt and the two
@@ -148,11 +151,11 @@ __device__ inline void narrow_test(const DevScene<R>& sc, const G& geo, uint32_t
     auto inside = [&](R t) {
         return (tmin < t) && (t < best.t || (t == best.t && best.idx != 0xFFFFFFFFu && sc.orig_id[i] < sc.orig_id[best.idx]));
     };
-    R t = (h - sq) / a;
+    R t = root_over_a(h - sq, ra);
     bool ok = inside(t);
     if (!ok) {
         MIRT_DIAG(sc, DG_NARROW_FAR, true);
-        t = (h + sq) / a;
+        t = root_over_a(h + sq, ra);
         ok = inside(t);
     }
     if (ok) {
@@ -478,41 +481,47 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
 #undef MIRT_CONS_PUSH
 }
 
-/* ---- f32, resident scenes: the broad phase on the matrix pipe -----------------------------------------
- * The two dot products of the conservative test, h = Dn.M - k1 and e = 2 O.M - k2 - w, are a (rays x K) x (K x spheres)
- * contraction with a tiny K.  One v_mfma_f32_32x32x16_f16 evaluates it for 32 rays x 32 spheres in 32 cycles - 1 cycle
- * per (wave, sphere, quantity) where the VALU needs 7-10 - and leaves 2 VALU instructions per pair: q = fma(h, h, e)
- * and the alignbit that collects its sign.  (The matrix core and the VALU of a SIMD do not run concurrently on gfx950 -
- * bench/mfma_overlap.hip: the times add - so the gain is the instruction count, 10.3 -> ~5 issue slots per pair.)
+/* ---- the broad phase on the matrix pipe ---------------------------------------------------------------
+ * The conservative test of trace_cons, q = h^2 + e >= 0 with h = Dn.M - k1 and e = 2 O.M - k2 - w, is a polynomial in the
+ * sphere's M whose coefficients depend on the ray alone:
+ *     q = sum_{i<=j} c_ij M_i M_j + sum_i l_i M_i + c0 - w,
+ *     c_ii = Dn_i^2, c_ij = 2 Dn_i Dn_j, l = 2 (O - k1 Dn), c0 = k1^2 - k2          (k1 = Dn.O, k2 ~ |O|^2 less its margins)
+ * i.e. ONE (rays x K) x (K x spheres) contraction: sphere side M_i M_j (6), M_i (3), 1, w; ray side the coefficients.  Two
+ * chained v_mfma_f32_32x32x16_f16 (K = 32) evaluate it for 32 rays x 32 spheres in 64 cycles and leave ONE VALU instruction
+ * per pair, the v_alignbit that collects the sign of q (round 1 had the two dot products on the matrix pipe and h*h + e on
+ * the vector ALU: 2 per pair; the vector-ALU loop needs 9).  About 4.5 VALU instructions per MFMA issue for free in its
+ * shadow (bench/mfma_coexec.hip), so a tile of 4 MFMA + 39 VALU costs ~170 SIMD-cycles against ~230 before.
  *
- * Precision.  f16 operands carry 11 bits, so every f32 value x is split x ~ xh + xl (xh = f16(x), xl = f16(x - xh),
- * |x - xh - xl| <= max(2^-22 |x|, 2^-25)) and every product uses all four partial products (hh, hl, lh, ll): K = 12
- * for a 3-vector dot product + 2 + 2 for the split scalars = 16.  f16 x f16 products are exact in the f32 accumulator,
- * f16 subnormals are honoured, and the accumulation is off by <= 2^-22.8 of the sum of |terms| (bench/mfma_probe.hip,
- * budgeted here as a = 2^-21).  Everything is evaluated in the scene's power-of-two scale (mx_scale: exact in f32),
- * chosen so that max(|M|+rho) <= 64: all operands stay far inside the f16 range as long as |O|^2 <= MIRT_MX_K2MAX,
- * which holds for every ray that starts on a sphere; a ray that violates it (far camera: the host then picks the
- * VALU kernel anyway; NaN) simply keeps every sphere as a candidate.
- *   K layout (ray value x sphere value), identical sphere operand for both products:
- *     k0-3   x: (dh,mh) (dh,ml) (dl,mh) (dl,ml)      k4-7 y likewise      k8-11 z likewise
- *     k12,13 (-k1h, 1) (-k1l, 1)   |  (-k2h, 1) (-k2l, 1)                 k14,15 (0, wh) (0, wl)  |  (-1, wh) (-1, wl)
- *   with u = 2^-22, f = 2^-25 (half the f16 subnormal spacing), everything in scaled units and |Dn| <= 1.0001:
- *     |dh| <= (2u + 1.01a)(|M| + |O|) + f (2.8 + 1.75 |M|)
- *     |de| <= (2u + 1.01a)(|O| + |M|)^2 + 1.01 a rho^2 + 1.75 f (2|O| + |M|)        (w and k2 are rounded one-sidedly)
- *     |dq| <= 2|h| dh + dh^2 + de <= 50.4 eps ((|M|+|O|)^2 + rho^2) + f (7.35 |M| + 9.1 |O|)   (the fma itself cannot flip a sign)
- *   Together with the 32 eps of "exact discriminant >= 0 => the line passes the ball" and 40 eps for the f32 ray-side
- *   constants (trace_cons) the relative part stays below 128 eps ((|M|+|O|)^2 + rho^2) <= 256 eps (|M|^2 + |O|^2 + rho^2);
- *   the absolute part (9.1 f < 2^-21) is linear in |M| and |O|.  So the records carry
+ * Precision.  f16 operands carry 11 bits, so every value x is split x ~ xh + xl (xh = f16(x), xl = f16(x - xh),
+ * |x - xh - xl| <= max(2^-22 |x|, 2^-25) =: delta(x), |xl| <= 2^-11 |x| + 2^-25) and every product x y takes the three
+ * partial products xh yh + xh yl + xl yh: off by xl yl + delta(x) |y| + |x| delta(y) <= 3 * 2^-22 |x||y| + 2^-25 (|x| + |y|)
+ * (+ terms of order 2^-36).  f16 x f16 products are exact in the f32 accumulator, f16 subnormals are honoured, and the
+ * accumulation of one MFMA is off by <= 2^-22.8 of the sum of |terms| (bench/mfma_probe.hip); two chained ones by
+ * <= 2^-21.8, budgeted as a = 2^-21.  Everything is evaluated in the scene's power-of-two scale (mx_scale: exact in f32),
+ * chosen so that max(|M|+rho) <= 64 (products M_i M_j <= 4096, l_i <= 380, c0 <= 36000: all inside the f16 range) as long
+ * as |O|^2 <= MIRT_MX_K2MAX, which holds for every ray that starts on a sphere; a ray that violates it (far camera: the
+ * host then picks the VALU kernel anyway; NaN) simply keeps every sphere as a candidate.
+ *   K slots (ray value x sphere value); p runs over the nine products xx yy zz xy xz yz | x y z:
+ *     3p, 3p+1, 3p+2   (ch, Ph) (ch, Pl) (cl, Ph)         27-29  (c0h, 1) (c0m, 1) (c0l, 1)  (c0 split three ways)
+ *     30, 31           (-1, wh) (-1, wl)                   (w rounded one-sidedly on the host: wh + wl <= w)
+ *   Error of the evaluated q against the real-number q of the exact Dn, O, M, with eps = 2^-24, in scaled units, |Dn| <= 1.0001:
+ *     sum of |terms| <= |M|^2 (quadratic) + 2 |O||M| (linear) + |O|^2 + |M|^2 + rho^2  <=  2 (|M|+|O|)^2 + rho^2
+ *     partial products       12 eps (|M|^2 + 2|O||M|)  <= 12 eps (|M|+|O|)^2      + 2^-25 (4.1 + 1.8 |M| + 3.6 |O|)
+ *     accumulation            8 eps (2 (|M|+|O|)^2 + rho^2)
+ *     f32 coefficients        c_ij: 9 eps |M|^2 (Dn = d * rsq(a): 4 eps per component), l: 26 eps |O||M|, c0: 19 eps |O|^2
+ *                             <= 19 eps (|M|+|O|)^2
+ *   Together with the 32 eps of "exact discriminant >= 0 => the line passes the ball" the relative part is
+ *   <= 79 eps (|M|+|O|)^2 + 8 eps rho^2, inside the 128 eps ((|M|+|O|)^2 + rho^2) <= 256 eps (|M|^2 + |O|^2 + rho^2) that
+ *   the margins provide; the absolute part 2^-25 (4.1 + 1.8 |M| + 3.6 |O|) is linear.  So the records carry
  *   w = |M|^2 - rho^2 - 256 eps (|M|^2 + rho^2) - 2^-21 |M| (rounded down in the split) and the ray
- *   k2 = |O|^2 (1 - 335 eps) - 2^-20.9 |O| - 2^-24 (the last term covers the split of k2 itself).  The absolute part is
- *   what limits the dynamic range: where it is not small against rho^2 for most spheres (radius-0.01 spheres on a
- *   radius-1e5 ground) the host keeps the scene on the VALU kernel.  -DMIRT_VERIFY_BROAD re-tests every pair exactly
- *   here as well.
+ *   k2 = |O|^2 (1 - 335 eps) - 2^-20.9 |O| - 5.4 * 2^-25.  The absolute part is what limits the dynamic range: where it is
+ *   not small against rho^2 for most spheres (radius-0.01 spheres on a radius-1e5 ground) the host keeps the scene on the
+ *   VALU kernel.  -DMIRT_VERIFY_BROAD re-tests every pair exactly here as well.
  *   Operand lanes: sphere rows come from the A operand (lane l: row l % 32, K half l / 32), rays are the columns (B
- *   operand, lane l: ray l % 32, K half l / 32), so the wave's 64 rays take two MFMAs per product and each lane
- *   supplies one K half of its own ray and receives the other lane's half by v_permlane32_swap; a result lane holds
- *   16 of the 32 rows of one column - rows are ordered so that these are 16 consecutive sorted spheres - and the same
- *   swap brings the two 16-bit words of a ray together.  The entry lists and the narrow phase are trace_cons's. */
+ *   operand, lane l: ray l % 32, K half l / 32), so the wave's 64 rays take two chains per tile and each lane supplies one
+ *   K half of its own ray and receives the other lane's half by v_permlane32_swap; a result lane holds 16 of the 32 rows of
+ *   one column - rows are ordered so that these are 16 consecutive sorted spheres - and the same swap brings the two
+ *   16-bit words of a ray together.  The entry lists and the narrow phase are trace_cons's. */
 #define MIRT_MX_K2MAX 36000.0f
 #ifndef MIRT_MX_MARGIN_TEST /* diagnostic builds: scale every margin of trace_mx (1 = the derived ones) to see how much slack they carry */
 #define MIRT_MX_MARGIN_TEST 1.0
@@ -987,8 +996,13 @@ template <class R, class G> __device__ inline Hit<R> make_hit(const DevScene<R>&
     V3<R> C = {sa.x, sa.y, sa.z};
     if (c.idx >= sc.n_static) C = center_at(C, V3<R>{sb.x, sb.y, sb.z}, ray.tm);
     Hit<R> h;
-    h.p = ray.o + ray.d * c.t;   /* ray.rs:27-29 */
-    h.on = (h.p - C) / sb.w;     /* sphere.rs:103 */
+    if constexpr (sizeof(R) == 8) {
+        h.p = ray.o + ray.d * c.t;   /* ray.rs:27-29 */
+        h.on = (h.p - C) / sb.w;     /* sphere.rs:103 */
+    } else { /* f32 spec: fused o + t d; B.w holds 1 / r (one division per sphere on the host instead of three per hit) */
+        h.p = {__builtin_fmaf(ray.d.x, c.t, ray.o.x), __builtin_fmaf(ray.d.y, c.t, ray.o.y), __builtin_fmaf(ray.d.z, c.t, ray.o.z)};
+        h.on = (h.p - C) * sb.w;
+    }
     h.front = dot(ray.d, h.on) < (R)0.0;
     h.n = h.front ? h.on : -h.on;
     return h;
@@ -1150,7 +1164,9 @@ template <class R> __device__ inline V3<R> lambertian_attenuation(const DevScene
     i = i < m.img_w - 1 ? i : m.img_w - 1;
     j = j < m.img_h - 1 ? j : m.img_h - 1;
     uint32_t px = sc.texels[m.img_offset + j * m.img_w + i];
-    return V3<R>{(R)(px & 0xFFu) / (R)255.0, (R)((px >> 8) & 0xFFu) / (R)255.0, (R)((px >> 16) & 0xFFu) / (R)255.0} / m.reflectance;
+    const V3<R> byte = {(R)(px & 0xFFu), (R)((px >> 8) & 0xFFu), (R)((px >> 16) & 0xFFu)};
+    if constexpr (sizeof(R) == 8) return V3<R>{byte.x / (R)255.0, byte.y / (R)255.0, byte.z / (R)255.0} / m.reflectance; /* texture.rs:91-93, material.rs:78 */
+    else return byte * m.inv_scale; /* f32 spec: inv_scale = (1 / 255) / reflectance, taken once on the host */
 }
 
 /* ---- materials: scene/material.rs ----------------------------------------------------------------- */
