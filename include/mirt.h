@@ -115,7 +115,7 @@ typedef struct mirt_camera {
 
 typedef enum mirt_precision {
     MIRT_F64 = 64, /* parity mode: the reference's arithmetic, operation for operation       */
-    MIRT_F32 = 32  /* throughput mode: binary32, fused discriminant (see DESIGN.md "f32 spec") */
+    MIRT_F32 = 32  /* throughput mode: binary32 in the "f32 spec" of DESIGN.md 3 (running product, perpendicular-form discriminant, reciprocals) */
 } mirt_precision;
 
 #define MIRT_FLAG_COMPACT_ROWS 1u /* outputs hold only the rows this call owns, packed in row order */
@@ -124,7 +124,7 @@ typedef enum mirt_precision {
  * Bvh::hit (src/scene/bvh.rs:78-92) for scenes where testing every sphere is not affordable. */
 #define MIRT_FLAG_BVH 2u
 /* Brute-force loop (either precision): keep the broad phase on the vector ALU.  By default scenes whose extents fit the
- * split-f16 operands run the broad phase's dot products on the matrix pipe (v_mfma_f32_32x32x16_f16); the candidates go
+ * split-f16 operands run the broad phase's conservative test on the matrix pipe (v_mfma_f32_32x32x16_f16); the candidates go
  * through the same exact test either way, so the (id, t) of every ray - and the image - do not depend on this flag. */
 #define MIRT_FLAG_VALU_BROAD 4u
 /* Device-buffer render calls: do not wait for the launch.  The call records its timing events and sends the counters to

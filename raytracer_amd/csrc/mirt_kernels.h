@@ -10,12 +10,12 @@
  * Closest-hit query: brute force over all spheres, as an n-body style tile loop, or - on request, f32 only - a
  * bounding-volume tree (`trace_bvh`).
  *   broad phase : every lane tests every sphere.  `trace_mx` (the default, either precision): a conservative bounding-ball
- *                 test whose two dot products run on the matrix pipe (split-f16 operands, v_mfma_f32_32x32x16_f16) and
- *                 leave 2 VALU per pair; `trace_cons` (f32): the same test in 8 VALU per pair, records from LDS as
+ *                 test evaluated whole on the matrix pipe (split-f16 operands, two chained v_mfma_f32_32x32x16_f16), which
+ *                 leaves 1 VALU per pair; `trace_cons` (f32): the same test in 8 VALU per pair, records from LDS as
  *                 wave-uniform broadcasts; `trace` (f64): the discriminant d of sphere.rs:81-90 itself.  Lanes only
  *                 remember WHICH spheres may be hit (a short per-lane list in LDS).
  *   narrow phase: each lane then walks its own list and runs the exact root selection of sphere.rs:91-101
- *                 (sqrt, true divisions, strict interval) - a few iterations per lane instead of one
+ *                 (sqrt, true divisions in f64 / the ray's reciprocal in the f32 spec, strict interval) - a few iterations per lane instead of one
  *                 divergent slow path per (wave, sphere).
  * Results are identical to testing the spheres one after the other in insertion order with a shrinking
  * interval (ties in t go to the lowest hit id), which is what the reference's BVH walk computes.
