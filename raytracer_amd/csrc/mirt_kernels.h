@@ -335,16 +335,24 @@ __device__ inline float filter_sqrt(float x) { return __builtin_amdgcn_sqrtf(x);
 #ifndef MIRT_ENT_CAP
 #define MIRT_ENT_CAP 16
 #endif
+#define MIRT_F32_LDS_MATS 512u
 struct F32Lds {
     float4 S[MIRT_LDS_RECORDS];
     float4 A[MIRT_LDS_RECORDS];
     float4 B[MIRT_LDS_RECORDS];
     uint16_t mat[MIRT_LDS_RECORDS];
     uint32_t ent[MIRT_F32_WAVES][MIRT_ENT_CAP][MIRT_WAVE];
+    DevMaterial<float> mats[MIRT_F32_LDS_MATS]; /* the scene's materials when they fit (36 KB): a bounce starts with this record */
     /* all threads of the block; true when the scene is resident */
     __device__ inline bool fill(const DevScene<float>& sc) {
         const uint32_t nrec = (sc.n + MIRT_CGROUP - 1) / MIRT_CGROUP * MIRT_CGROUP;
         const bool res = nrec <= MIRT_LDS_RECORDS && sc.n_materials <= 0x10000u;
+        if (sc.n_materials <= MIRT_F32_LDS_MATS) {
+            const uint32_t nd = sc.n_materials * (uint32_t)(sizeof(DevMaterial<float>) / 4);
+            const uint32_t* src = (const uint32_t*)sc.mats;
+            uint32_t* dst = (uint32_t*)mats;
+            for (uint32_t i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+        }
         if (res) {
             for (uint32_t i = threadIdx.x; i < nrec; i += blockDim.x) {
                 S[i] = sc.S[i]; /* padded to whole tiles on the host */
@@ -1060,7 +1068,12 @@ template <bool RES> struct TracerF32 {
         return make_hit(sc, GeomGlobal<float>{sc}, c, ray);
     }
     __device__ inline uint32_t material(uint32_t idx) const { return RES ? (uint32_t)L.mat[idx] : sc.material[idx]; }
-    __device__ inline const DevMaterial<float>& material_record(uint32_t idx) const { return sc.mats[material(idx)]; }
+    /* by value: the record may come from the LDS copy or from HBM/L2 (two address spaces) */
+    __device__ inline DevMaterial<float> material_record(uint32_t idx) const {
+        const uint32_t m = material(idx);
+        if (sc.n_materials <= MIRT_F32_LDS_MATS) return L.mats[m];
+        return sc.mats[m];
+    }
 };
 
 template <bool RES, class LDS = MxLds> struct TracerF32Mx {
