@@ -116,6 +116,33 @@ def test_stress_scene_radiance_bit_exact(oracle, prec):
     assert np.array_equal(bits(lin), bits(o_lin))
 
 
+@pytest.mark.parametrize("n", [505, 512, 513, 700, 1024])
+def test_f32_radiance_bit_exact_across_the_lds_layouts(oracle, n):
+    """The matrix-pipe kernel has two LDS layouts: up to 512 sorted slots with 640 material records, up to 1024 slots with
+    184 (these scenes have ~0.9 n materials: LDS copy below 513, HBM/L2 above).  Either side of the boundary the frame is
+    the oracle's f32-spec frame bit for bit, and the vector-ALU kernel's."""
+    sc, cam = presets.stress_scene(n, 3), presets.stress_camera(96, 3, 12)
+    assert cam.closest_hit_kind(sc, precision=abi.F32) == "matrix"
+    lin, rgb8 = cam.render_arrays(sc, precision=abi.F32, seed=8)
+    seg = cam.last_stats["segments"]
+    o_lin, o_rgb8, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F32, seed=8, threads=8, spec_chunk=cam.pass_granularity(precision=abi.F32))
+    assert seg == o_seg and np.array_equal(bits(lin), bits(o_lin)) and np.array_equal(rgb8, o_rgb8)
+    v_lin, _ = cam.render_arrays(sc, precision=abi.F32, seed=8, accel="valu")
+    assert cam.last_stats["segments"] == seg and np.array_equal(bits(v_lin), bits(lin))
+
+
+def test_f32_paths_are_as_long_as_f64_paths_from_a_far_camera():
+    """Regression for the f32 discriminant: with d = h^2 - a (|oc|^2 - r^2) in binary32 a camera 95 units from
+    radius-0.1..0.5 spheres put hit points inside the spheres and the 10 000-sphere frame traced 60 % more segments than in
+    binary64.  The two precisions draw different random numbers, so the counts agree statistically, not exactly."""
+    sc, cam = presets.stress_scene(10000, 1), presets.stress_camera(480, 4, 50)
+    cam.render_arrays(sc, precision=abi.F32, seed=1, want_linear=False)
+    seg32 = cam.last_stats["segments"]
+    cam.render_arrays(sc, precision=abi.F64, seed=1, want_linear=False)
+    seg64 = cam.last_stats["segments"]
+    assert abs(seg32 - seg64) < 0.01 * seg64, (seg32, seg64)
+
+
 @pytest.mark.parametrize("prec", [abi.F64, abi.F32])
 def test_textured_lens_scenes_are_bit_equal_almost_everywhere(oracle, prec):
     """With the image texture and the lens back in (the bench scene and camera), what is left between the two sides is the

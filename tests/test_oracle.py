@@ -390,3 +390,19 @@ def test_independent_python_render_equals_the_cpp_oracle(oracle, name, width, sp
         assert np.array_equal(np.asarray(q8, np.uint8), o_rgb8)
     for k, (ctr, key) in enumerate([((0, 0, 0, 0), (0, 0)), ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2), ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0))]):
         assert list(oracle_np.philox4x32_10(ctr, key)) == oracle.philox(ctr, key)
+
+
+def test_f32_spec_paths_are_as_long_as_f64_paths_from_a_far_camera():
+    """The f32 spec's discriminant goes through the perpendicular to the line (oracle.cpp Disc<float>): with the textbook
+    form in binary32 this frame (camera 95 units from radius-0.1..0.5 spheres) traced 49 023 segments against 30 596 in
+    binary64 - hit points inside the spheres, rays re-hitting them from within.  Different random numbers in the two
+    precisions: the counts agree statistically."""
+    from oracle import binding as ob
+    from raytracer_amd import abi, presets
+
+    sc, cam = presets.stress_scene(10000, 1), presets.stress_camera(96, 4, 50)
+    seg = {}
+    for prec, chunk in ((abi.F64, 0), (abi.F32, 4)):
+        _, _, seg[prec], nan = ob.render(sc.flat, cam.pod, precision=prec, seed=1, use_bvh=True, threads=8, want_rgb8=False, spec_chunk=chunk)
+        assert nan == 0
+    assert abs(seg[abi.F32] - seg[abi.F64]) < 0.02 * seg[abi.F64], seg
