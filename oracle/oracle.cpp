@@ -199,12 +199,48 @@ template <> struct Disc<float> {
     }
 };
 
+/* acos / atan2 of Sphere::uv.  double: the math library's, as Rust's f64 methods.  float: the f32 spec's polynomial forms
+ * (Abramowitz & Stegun 4.4.46 / 4.4.49), operation for operation as mirt_device.h::m_acos / m_atan2. */
+static inline double uv_acos(double x) { return std::acos(x); }
+static inline double uv_atan2(double y, double x) { return std::atan2(y, x); }
+static inline float uv_acos(float x) {
+    const float ax = std::fabs(x);
+    float p = -0.0012624911f;
+    p = std::fmaf(p, ax, 0.0066700901f);
+    p = std::fmaf(p, ax, -0.0170881256f);
+    p = std::fmaf(p, ax, 0.0308918810f);
+    p = std::fmaf(p, ax, -0.0501743046f);
+    p = std::fmaf(p, ax, 0.0889789874f);
+    p = std::fmaf(p, ax, -0.2145988016f);
+    p = std::fmaf(p, ax, 1.5707963050f);
+    const float r = std::sqrt(1.0f - ax) * p;
+    return x < 0.0f ? 3.14159265358979323846f - r : r;
+}
+static inline float uv_atan2(float y, float x) {
+    const float ax = std::fabs(x), ay = std::fabs(y);
+    const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    const float t = mx == 0.0f ? 0.0f : mn / mx;
+    const float z = t * t;
+    float q = 0.0028662257f;
+    q = std::fmaf(q, z, -0.0161657367f);
+    q = std::fmaf(q, z, 0.0429096138f);
+    q = std::fmaf(q, z, -0.0752896400f);
+    q = std::fmaf(q, z, 0.1065626393f);
+    q = std::fmaf(q, z, -0.1420889944f);
+    q = std::fmaf(q, z, 0.1999355085f);
+    q = std::fmaf(q, z, -0.3333314528f);
+    q = std::fmaf(q, z, 1.0f);
+    float r = t * q;
+    r = ay > ax ? 1.57079632679489661923f - r : r;
+    r = x < 0.0f ? 3.14159265358979323846f - r : r;
+    return y < 0.0f ? -r : r;
+}
 /* sphere.rs:72-76 */
 template <class R> static inline void sphere_uv(V3<R> p, R& u, R& v) {
     const R PI = (R)3.14159265358979323846264338327950288;
     const R FRAC_1_PI = (R)0.318309886183790671537767526745028724;
-    R theta = -std::acos(p.y);
-    R phi = -std::atan2(p.z, p.x) + PI;
+    R theta = -uv_acos(p.y);
+    R phi = -uv_atan2(p.z, p.x) + PI;
     u = (R)0.5 * phi * FRAC_1_PI;
     v = theta * FRAC_1_PI;
 }

@@ -49,9 +49,44 @@ __device__ inline float m_floor(float x) { return floorf(x); }
 __device__ inline double m_floor(double x) { return floor(x); }
 __device__ inline float m_round(float x) { return roundf(x); }
 __device__ inline double m_round(double x) { return round(x); }
-__device__ inline float m_acos(float x) { return acosf(x); }
+/* Sphere::uv (sphere.rs:72-76).  double: the math library's acos / atan2, as Rust's f64 methods.  float (f32 spec): the two
+ * polynomial forms of Abramowitz & Stegun 4.4.46 / 4.4.49 (|error| <= 2.2e-8 / 1.4e-8 before rounding), every step an IEEE
+ * operation or an explicit fma, restated operation for operation in the oracle - the angles only choose a texel, and with
+ * them spelled out an image-textured f32 frame is the oracle's bit for bit (OCML's acosf / atan2f differ from glibc's in
+ * the last ulp now and then, which moved a texel choice in ~0.1 % of the channels).  |x| > 1 gives NaN like acos itself. */
+__device__ inline float m_acos(float x) {
+    const float ax = __builtin_fabsf(x);
+    float p = -0.0012624911f;
+    p = __builtin_fmaf(p, ax, 0.0066700901f);
+    p = __builtin_fmaf(p, ax, -0.0170881256f);
+    p = __builtin_fmaf(p, ax, 0.0308918810f);
+    p = __builtin_fmaf(p, ax, -0.0501743046f);
+    p = __builtin_fmaf(p, ax, 0.0889789874f);
+    p = __builtin_fmaf(p, ax, -0.2145988016f);
+    p = __builtin_fmaf(p, ax, 1.5707963050f);
+    const float r = sqrtf(1.0f - ax) * p;
+    return x < 0.0f ? 3.14159265358979323846f - r : r;
+}
 __device__ inline double m_acos(double x) { return acos(x); }
-__device__ inline float m_atan2(float y, float x) { return atan2f(y, x); }
+__device__ inline float m_atan2(float y, float x) {
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    const float t = mx == 0.0f ? 0.0f : mn / mx;
+    const float z = t * t;
+    float q = 0.0028662257f;
+    q = __builtin_fmaf(q, z, -0.0161657367f);
+    q = __builtin_fmaf(q, z, 0.0429096138f);
+    q = __builtin_fmaf(q, z, -0.0752896400f);
+    q = __builtin_fmaf(q, z, 0.1065626393f);
+    q = __builtin_fmaf(q, z, -0.1420889944f);
+    q = __builtin_fmaf(q, z, 0.1999355085f);
+    q = __builtin_fmaf(q, z, -0.3333314528f);
+    q = __builtin_fmaf(q, z, 1.0f);
+    float r = t * q;
+    r = ay > ax ? 1.57079632679489661923f - r : r;
+    r = x < 0.0f ? 3.14159265358979323846f - r : r;
+    return y < 0.0f ? -r : r;
+}
 __device__ inline double m_atan2(double y, double x) { return atan2(y, x); }
 __device__ inline float m_sin(float x) { return sinf(x); }
 __device__ inline double m_sin(double x) { return sin(x); }

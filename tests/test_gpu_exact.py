@@ -7,8 +7,9 @@ so equal operation ORDER must give equal bits:
     a0 (a1 (... sky)) of camera.rs:277 and the sequential sample sum of camera.rs:242-246;
   * MIRT_F32 (throughput mode, the bench kernels) against the oracle's f32 instantiation of the f32 spec - running
     product per path, per-work-item sums added in chunk order (oracle.cpp::color_running_product / render_rows).
-Scenes with image textures or a lens are held to "almost every channel bit-equal": OCML and glibc differ in the last ulp
-of acos/atan2/sin/cos, which moves a texel choice or a ray origin now and then.
+In f64, scenes with image textures or a lens are held to "almost every channel bit-equal": OCML and glibc differ in the last
+ulp of acos/atan2/sin/cos, which moves a texel choice or a ray origin now and then.  The f32 spec spells these functions
+out (mirt_device.h::lens_sincos, m_acos, m_atan2; restated in the oracle), so every f32 frame is held to bit-equality.
 """
 import ctypes as C
 import math
@@ -161,6 +162,8 @@ def test_textured_lens_scenes_are_bit_equal_almost_everywhere(oracle, prec):
     close = float((np.abs(lin - o_lin) <= tol * (1 + np.abs(o_lin))).mean())
     print(f"precision {prec}: bit-equal channels {same:.4f}, within tolerance {close:.4f}")
     assert close >= 0.995
+    if prec == abi.F32:  # the f32 spec spells out its own sin/cos (lens) and acos/atan2 (Sphere::uv): nothing is left to a math library
+        assert same == 1.0
     # without the lens only the textured sphere's uv is left
     cam2 = lensless_camera(160, 8)
     lin2, _ = cam2.render_arrays(sc, precision=prec, seed=2)
@@ -171,6 +174,19 @@ def test_textured_lens_scenes_are_bit_equal_almost_everywhere(oracle, prec):
     same2 = float((bits(lin2) == bits(o2)).mean())
     print(f"precision {prec}, no lens: bit-equal channels {same2:.5f}")
     assert same2 >= 0.999
+    if prec == abi.F32:
+        assert same2 == 1.0
+
+
+@pytest.mark.parametrize("accel", [None, "valu", "bvh"])
+def test_f32_textured_presets_bit_exact(oracle, accel):
+    """Round 2: every f32 frame is the oracle's bit for bit, image textures and lens included - the textured C4 scene (two
+    image spheres, checker ground, lens) and the reference's default mars scene, through every closest-hit front end."""
+    for sc, cam, seed in ((presets.textured_scene(), presets.textured_camera(192, 6, 50), 3), (presets.mars_texture_scene(), presets.default_camera(160, 9, 50), 4)):
+        lin, rgb8 = cam.render_arrays(sc, precision=abi.F32, seed=seed, accel=accel)
+        o_lin, o_rgb8, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F32, seed=seed, threads=8, spec_chunk=cam.pass_granularity(precision=abi.F32))
+        assert cam.last_stats["segments"] == o_seg
+        assert np.array_equal(bits(lin), bits(o_lin)) and np.array_equal(rgb8, o_rgb8)
 
 
 def test_reference_default_render_c1(oracle):

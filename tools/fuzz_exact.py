@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Fuzz of the bit-exact radiance bar (tests/test_gpu_exact.py): random scenes of every material and the two procedural textures
-(no image texture: acos/atan2 are libm's), moving spheres, random cameras, depths and sample counts.
+(image textures only with FUZZ_IMAGES=1, which renders in f32 alone: in f64 acos/atan2 are libm's), moving spheres, random cameras, depths and sample counts.
   f64: no lens (sin/cos are libm's); GPU (matrix-pipe filter and all-f64 loop) must equal the oracle's reference-order render bit for bit.
   f32: lens on or off (the f32 spec's own sin/cos); GPU (matrix pipe, vector ALU, tree) must equal the oracle's f32-spec render bit for bit,
        with a random lower bound on the samples per work item.
-usage: fuzz_exact.py [first_seed] [cases]      (FUZZ_MAX_N: spheres per scene, default 140)"""
+usage: fuzz_exact.py [first_seed] [cases]      (FUZZ_MAX_N: spheres per scene, default 140; FUZZ_IMAGES=1: f32 only, with random image textures)"""
 import os
 import sys
 
@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import binding  # noqa: E402
 from raytracer_amd import abi, api  # noqa: E402
-from raytracer_amd.api import Camera, CheckerTexture, Dielectric, Lambertian, Metal, Scene, Sphere  # noqa: E402
+from raytracer_amd.api import Camera, CheckerTexture, Dielectric, ImageTexture, Lambertian, Metal, Scene, Sphere  # noqa: E402
+
+IMAGES = os.environ.get("FUZZ_IMAGES") == "1"
 
 binding.load()
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
@@ -32,6 +34,9 @@ for case in range(n_cases):
 
     def material():
         k = rng.random()
+        if IMAGES and k < 0.25:  # the f32 spec's own acos / atan2 pick the texel: odd sizes, 1 x 1 included
+            img = rng.integers(0, 256, (int(rng.integers(1, 40)), int(rng.integers(1, 70)), 3), dtype=np.uint8)
+            return Lambertian.with_texture(ImageTexture(img), float(rng.uniform(0.4, 1.0)))
         if k < 0.35:
             return Lambertian.new(tuple(rng.uniform(0.05, 0.95, 3)), float(rng.uniform(0.3, 1.0)))
         if k < 0.55:
@@ -64,7 +69,7 @@ for case in range(n_cases):
     lens = float(rng.choice([0.0, 0.01, 0.05]))
     seed = seed0 + case
     msgs = []
-    for prec in (abi.F64, abi.F32):
+    for prec in ((abi.F32,) if IMAGES else (abi.F64, abi.F32)):
         cam = Camera.build(tuple(d * dist), (0.0, 0.2 * ext, 0.0), None, W, ratio, spp, vfov, dist, 0.0 if prec == abi.F64 else lens, depth)
         cam.chunk_samples = int(rng.choice([0, 0, 2, 4])) if prec == abi.F32 else 0
         g = max(1, cam.pass_granularity(precision=prec))
@@ -79,6 +84,6 @@ for case in range(n_cases):
                 bad += 1
                 diff = int((bits(lin) != bits(o_lin)).sum())
                 msgs.append(f"MISMATCH f{prec} accel {accel}: {diff} channels differ, segments {cam.last_stats['segments']} vs {o_seg}")
-    print(f"case {seed}: n={n} {W}x{cam.height}x{spp} depth {depth} lens(f32) {lens} Q {g} " + ("; ".join(msgs) if msgs else "bit-equal (f64 x2, f32 x3)"), flush=True)
+    print(f"case {seed}: n={n} {W}x{cam.height}x{spp} depth {depth} lens(f32) {lens} Q {g} " + ("; ".join(msgs) if msgs else ("bit-equal (f32 x3, image textures)" if IMAGES else "bit-equal (f64 x2, f32 x3)")), flush=True)
 print(f"cases {n_cases}  renders not bit-equal to the oracle: {bad}")
 sys.exit(1 if bad else 0)
