@@ -364,7 +364,7 @@ static int mx_ensure(const mirt_scene* s, const mirt_scene::MxSet& set, int e) {
     const double sc = std::ldexp(1.0, e);
     const double eps = 1.0 / 16777216.0, F = 1.0 / 2097152.0; /* 2^-24, 2^-21 */
     const size_t ntiles = (balls.size() + 31) / 32;
-    std::vector<uint4> SM((ntiles + 1) * 128); /* + one tile: the streaming loop prefetches one ahead */
+    std::vector<uint4> SM((ntiles + MIRT_RING_TILES + 1) * 128); /* + one tile: the streaming loop prefetches one ahead; + a chunk: trace_mx_ring stages whole chunks */
     auto split = [](double x, _Float16& h, _Float16& l) {
         h = (_Float16)x;
         l = (_Float16)(x - (double)h);
@@ -543,7 +543,7 @@ static int occupancy_of(const void* fn, int block) {
 
 /* the two render kernels behind one name */
 static const void* render_fn(double, int bvh) { return bvh == 3 ? (const void*)render_kernel_f64_mx : (const void*)render_kernel_f64<2>; }
-static const void* render_fn(float, int bvh) { return bvh == 4 ? (const void*)render_kernel_f32_tiny : bvh == 5 ? (const void*)render_kernel_f32_mx<MxLdsSmall> : bvh == 3 ? (const void*)render_kernel_f32_mx<MxLds> : bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
+static const void* render_fn(float, int bvh) { return bvh == 4 ? (const void*)render_kernel_f32_tiny : bvh == 6 ? (const void*)render_kernel_f32_mx_ring : bvh == 5 ? (const void*)render_kernel_f32_mx<MxLdsSmall> : bvh == 3 ? (const void*)render_kernel_f32_mx<MxLds> : bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
 static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam,
                                  const DevPart& part, const RenderParams& rp, double* partial, DevStats* stats, double* att) {
     if (bvh == 3) hipLaunchKernelGGL(render_kernel_f64_mx, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats, att);
@@ -552,6 +552,7 @@ static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStre
 static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<float>& sc, const DevCamera<float>& cam,
                                  const DevPart& part, const RenderParams& rp, float* partial, DevStats* stats, float*) {
     if (bvh == 4) hipLaunchKernelGGL(render_kernel_f32_tiny, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    else if (bvh == 6) hipLaunchKernelGGL(render_kernel_f32_mx_ring, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh == 5) hipLaunchKernelGGL(render_kernel_f32_mx<MxLdsSmall>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh == 3) hipLaunchKernelGGL(render_kernel_f32_mx<MxLds>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh == 2) hipLaunchKernelGGL(render_kernel_f32_bvh_lds, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
@@ -565,8 +566,9 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
                          void* d_accum = nullptr) {
     /* closest-hit front end: 0 = brute force, VALU broad phase; 1 = tree in HBM/L2; 2 = tree, records and spheres resident in
      * LDS; 3 = brute force, broad phase on the matrix pipe; 4 = f32, a handful of spheres (render_kernel_f32_tiny);
-     * 5 = 3 with the LDS layout for scenes of up to MIRT_MX_SMALL_RECORDS sorted slots (f32) */
-    const int bvh = mx ? ((sizeof(R) == 4 && s->n <= MIRT_MX_SMALL_RECORDS) ? 5 : 3) : !use_bvh ? ((sizeof(R) == 4 && s->n_live <= MIRT_TINY_SCENE) ? 4 : 0) /* 4 = the f32 kernel for a handful of spheres */
+     * 5 = 3 with the LDS layout for scenes of up to MIRT_MX_SMALL_RECORDS sorted slots (f32); 6 = 3 for scenes beyond the LDS,
+     * operands through the block-wide ring (f32) */
+    const int bvh = mx ? (sizeof(R) == 4 ? (s->n <= MIRT_MX_SMALL_RECORDS ? 5 : s->n > MIRT_LDS_RECORDS ? 6 : 3) : 3) : !use_bvh ? ((sizeof(R) == 4 && s->n_live <= MIRT_TINY_SCENE) ? 4 : 0) /* 4 = the f32 kernel for a handful of spheres */
                     : (s->bvh_n_nodes <= MIRT_BVH_LDS_NODES && s->bvh_n_recs <= MIRT_LDS_RECORDS && s->n <= MIRT_LDS_RECORDS &&
                        s->bvh_depth <= MIRT_BVH_LDS_STACK && s->n_materials <= 0x10000u && s->bvh_root != MIRT_BVH_NONE) ? 2 : 1;
     const uint32_t block = (sizeof(R) == 4 && bvh != 1) ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;

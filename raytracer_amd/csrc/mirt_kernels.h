@@ -610,22 +610,11 @@ __device__ inline void mx_split(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
     asm volatile("" : "+v"(lo));
 }
-/* R = double (the parity-mode kernels): the same filter on the ray rounded to f32 - Dn is normalised in double first, so
- * direction and origin are each off by <= 2^-24 relatively, the f32 line passes within 5 eps (|M| + |O|) of the f64 one,
- * and 6 eps ((|M|+|O|)^2 + rho^2) replaces the 32 eps of the f32 derivation (an f64 discriminant needs ~1e-15) inside the
- * same 128 eps budget; the balls behind the operands are built around the f64 spheres (mirt_scene_create).  The narrow
- * phase is the exact f64 test. */
-template <class R, class LDS, bool RES>
-__device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint32_t lane, bool active, const RayT<R>& ray, R tmin,
-                                Closest<R>& best, uint32_t& narrow_count, PhaseTimer& pt) {
-    best.t = (R)INFINITY;
-    best.idx = 0xFFFFFFFFu;
-    const RayA<R> a_true = ray_a(ray.d);
-    const uint32_t ntiles = (sc.n + 31) / 32;
-    uint2(*ent2)[MIRT_WAVE] = reinterpret_cast<uint2(*)[MIRT_WAVE]>(L.ent[w]); /* one entry per tile: both 16-sphere halves */
-    /* ---- the ray's operands ---- */
-    mirt_h8 bx0, bx1, by0, by1;
-    {
+/* The ray side of the contraction: the ten coefficients of q, split, packed and exchanged between the half-waves (see the
+ * K-slot table above).  bx0 / bx1: B operands of the two chained MFMAs for rays 0-31, by0 / by1 for rays 32-63. */
+template <class R>
+__device__ inline void mx_ray_operands(const DevScene<R>& sc, const RayT<R>& ray, RayA<R> a_true, bool active, mirt_h8& bx0, mirt_h8& bx1, mirt_h8& by0,
+                                       mirt_h8& by1) {
         const R inv = filter_rsq(a_true.a);
         const V3<float> Dn = {(float)(ray.d.x * inv), (float)(ray.d.y * inv), (float)(ray.d.z * inv)};
         const V3<float> O = {(float)(ray.o.x * (R)sc.mx_scale), (float)(ray.o.y * (R)sc.mx_scale), (float)(ray.o.z * (R)sc.mx_scale)};
@@ -677,7 +666,23 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
         }
         bx0 = __builtin_bit_cast(mirt_h8, x0); by0 = __builtin_bit_cast(mirt_h8, y0);
         bx1 = __builtin_bit_cast(mirt_h8, x1); by1 = __builtin_bit_cast(mirt_h8, y1);
-    }
+}
+
+/* R = double (the parity-mode kernels): the same filter on the ray rounded to f32 - Dn is normalised in double first, so
+ * direction and origin are each off by <= 2^-24 relatively, the f32 line passes within 5 eps (|M| + |O|) of the f64 one,
+ * and 6 eps ((|M|+|O|)^2 + rho^2) replaces the 32 eps of the f32 derivation (an f64 discriminant needs ~1e-15) inside the
+ * same 128 eps budget; the balls behind the operands are built around the f64 spheres (mirt_scene_create).  The narrow
+ * phase is the exact f64 test. */
+template <class R, class LDS, bool RES>
+__device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint32_t lane, bool active, const RayT<R>& ray, R tmin,
+                                Closest<R>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+    best.t = (R)INFINITY;
+    best.idx = 0xFFFFFFFFu;
+    const RayA<R> a_true = ray_a(ray.d);
+    const uint32_t ntiles = (sc.n + 31) / 32;
+    uint2(*ent2)[MIRT_WAVE] = reinterpret_cast<uint2(*)[MIRT_WAVE]>(L.ent[w]); /* one entry per tile: both 16-sphere halves */
+    mirt_h8 bx0, bx1, by0, by1;
+    mx_ray_operands(sc, ray, a_true, active, bx0, bx1, by0, by1);
     /* sphere operands: the block-resident LDS copy, or (big scenes) straight from L1/L2 - every wave of the chip reads the
      * same 1 KB per tile, one coalesced 16-byte load per lane, the next tile's already on its way while this one is tested
      * (the array is padded by one tile) */
@@ -769,6 +774,103 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
         }
         pt.stamp(PH_NARROW);
     }
+}
+
+/* ---- f32, scenes that do not fit the LDS: the sphere operands through a block-wide LDS ring ----------------
+ * trace_mx's streaming loop has every wave fetch every tile for itself (2 KB per tile and wave through L1/L2: 239
+ * SIMD-cycles per tile against 191 for a resident scene).  Here the 16 waves of the block walk the tiles in step: the
+ * operand area of the LDS (64 KB) is a ring of two chunks of MIRT_RING_TILES tiles, each wave copies two 1 KB slabs of the
+ * NEXT chunk with global_load_lds_dwordx4 (no VGPRs, lane-linear image = the operand layout) while all of them test the
+ * current one, and one barrier per chunk hands the buffers over - 1/16 of the L1/L2 traffic.
+ * The price is that the waves are no longer free-running: every wave of the block must make every call with the same
+ * number of barriers (MIRT_RING chunks + 1, a function of the scene alone), so render_body keeps idle waves in the loop
+ * until the whole block is out of work (T::LOCKSTEP), and a wave without a ray still stages and waits. */
+#define MIRT_RING_TILES 16u
+template <class LDS>
+__device__ inline void trace_mx_ring(const DevScene<float>& sc, LDS& L, uint32_t w, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
+                                     Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+    static_assert(LDS::N_RECORDS * 4u >= 2u * MIRT_RING_TILES * 128u, "the operand area must hold two chunks");
+    static_assert(MIRT_F32_WAVES * 2u == MIRT_RING_TILES * 2u, "two slabs of a chunk per wave");
+    best.t = INFINITY;
+    best.idx = 0xFFFFFFFFu;
+    const RayA<float> a_true = ray_a(ray.d);
+    const uint32_t ntiles = (sc.n + 31) / 32, nch = (ntiles + MIRT_RING_TILES - 1u) / MIRT_RING_TILES;
+    const bool wave_live = __ballot(active) != 0ull; /* a wave without rays only stages and keeps the barriers */
+    uint2(*ent2)[MIRT_WAVE] = reinterpret_cast<uint2(*)[MIRT_WAVE]>(L.ent[w]);
+    mirt_h8 bx0 = {}, bx1 = {}, by0 = {}, by1 = {};
+    if (wave_live) mx_ray_operands(sc, ray, a_true, active, bx0, bx1, by0, by1);
+    /* slabs 2 w and 2 w + 1 of chunk c -> ring buffer c & 1 (the host pads the operand array by a whole chunk of zeros) */
+    auto stage = [&](uint32_t c) {
+        const uint4* src = sc.SM + ((size_t)c * MIRT_RING_TILES * 128u + (size_t)w * 128u + lane);
+        uint4* dst = L.SM + ((c & 1u) * MIRT_RING_TILES * 128u + w * 128u);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64), (__attribute__((address_space(3))) void*)(dst + 64), 16, 0, 0);
+    };
+    auto narrow = [&](uint32_t gbase, uint32_t cnt) {
+        uint32_t k = 0, m = 0, gi = 0;
+        for (;;) {
+            if (m == 0 && k < cnt) {
+                const uint2 e = ent2[k][lane];
+                ++k;
+                m = (~e.x & 0xFFFFu) | (~e.y << 16);
+                gi = (gbase + (e.x >> 16)) * MIRT_CGROUP + (MIRT_CGROUP - 1);
+            }
+            if (__ballot(m != 0) == 0ull) break;
+            if (m != 0) {
+                const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
+                m &= m - 1u;
+                narrow_test(sc, GeomGlobal<float>{sc}, gi - bit + (bit >= 16u ? 32u : 0u), ray, a_true, tmin, best);
+                ++narrow_count;
+            }
+        }
+    };
+    const uint32_t sub = lane >> 5;
+    stage(0);
+    __syncthreads(); /* waits for the copies (vmcnt) and for the other waves: also fences the previous call's readers */
+    uint32_t t = 0, cnt = 0, gbase = 0;
+    for (uint32_t c = 0; c < nch; ++c) {
+        if (c + 1u < nch) stage(c + 1u);
+        if (wave_live) {
+            const mirt_h8* buf = (const mirt_h8*)(L.SM + (c & 1u) * MIRT_RING_TILES * 128u);
+            const uint32_t t0 = c * MIRT_RING_TILES;
+            uint32_t t_end = t0 + MIRT_RING_TILES;
+            t_end = t_end < ntiles ? t_end : ntiles;
+            while (t < t_end) {
+                bool flush = false;
+                for (; t < t_end && !flush; ++t) {
+                    const mirt_h8 a0 = buf[(t - t0) * 128u + lane], a1 = buf[(t - t0) * 128u + 64u + lane];
+                    const mirt_f16v zero = {};
+                    uint32_t mx = 2 * t - gbase + sub, my = mx;
+                    mirt_f16v qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bx0, zero, 0, 0, 0);
+                    mirt_f16v qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, by0, zero, 0, 0, 0);
+                    qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bx1, qx, 0, 0, 0);
+                    qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, by1, qy, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = __builtin_amdgcn_alignbit(mx, __float_as_uint(qx[r]), 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) my = __builtin_amdgcn_alignbit(my, __float_as_uint(qy[r]), 31);
+                    auto sw = __builtin_amdgcn_permlane32_swap(mx, my, false, false);
+                    mx = sw[0];
+                    my = sw[1];
+                    ent2[cnt][lane] = make_uint2(mx, my);
+                    cnt += ((mx & my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
+                    flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull;
+                }
+                /* a full list, or 0x7FFF tiles behind the pass's first one (group numbers in the entries are 16 bit) */
+                if (flush || 2u * t - gbase >= 0xFFFEu) {
+                    pt.stamp(PH_BROAD);
+                    narrow(gbase, cnt);
+                    pt.stamp(PH_NARROW);
+                    cnt = 0;
+                    gbase = 2 * t;
+                }
+            }
+        }
+        __syncthreads(); /* the next chunk has landed (vmcnt) and nobody reads this one any more */
+    }
+    pt.stamp(PH_BROAD);
+    if (wave_live) narrow(gbase, cnt);
+    pt.stamp(PH_NARROW);
 }
 
 /* ---- a few rays left in the wave: spheres across the lanes ------------------------------------------
@@ -1105,6 +1207,26 @@ template <bool RES, class LDS = MxLds> struct TracerF32Mx {
     }
 };
 
+/* scenes beyond the LDS: the block's waves in step over an LDS ring of operand chunks (trace_mx_ring) */
+template <class LDS> struct TracerF32MxRing {
+    typedef float Real;
+    static constexpr bool RESUMABLE = false;
+    static constexpr bool LOCKSTEP = true; /* closest() holds block barriers: every wave of the block calls it the same number of times */
+    const DevScene<float>& sc;
+    LDS& L;
+    uint32_t w;
+    __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
+        trace_mx_ring<LDS>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
+    }
+    __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const { return make_hit(sc, GeomGlobal<float>{sc}, c, ray); }
+    __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }
+    __device__ inline DevMaterial<float> material_record(uint32_t idx) const {
+        const uint32_t m = material(idx);
+        if (sc.n_materials <= LDS::N_MATS) return L.mats[m];
+        return sc.mats[m];
+    }
+};
+
 template <bool RES> struct TracerF64Mx {
     typedef double Real;
     static constexpr bool RESUMABLE = false;
@@ -1417,6 +1539,10 @@ struct RenderParams {
  *     fit their budget) K2b then adds the samples of a pixel one after the other like the loop of camera.rs:242-245.
  *   f32 (throughput mode, the f32 spec of DESIGN.md): the running product thr = ((a0 a1) a2) ..., radiance = thr sky, and a
  *     pixel is the sum in chunk order of per-item sums; the oracle's f32 instantiation restates exactly this. */
+/* T::LOCKSTEP, where a tracer declares it */
+template <class T, class = void> struct tracer_lockstep { static constexpr bool value = false; };
+template <class T> struct tracer_lockstep<T, decltype((void)T::LOCKSTEP)> { static constexpr bool value = T::LOCKSTEP; };
+
 template <class T>
 __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, const DevCamera<typename T::Real>& cam, const DevPart& part,
                                    const RenderParams& rp, typename T::Real* __restrict__ partial, DevStats* __restrict__ stats, uint32_t lane,
@@ -1510,8 +1636,14 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 need_ray = has_work;
             }
         }
-        if (__ballot(has_work) == 0ull) break;
-        ++n_iter;
+        if constexpr (tracer_lockstep<T>::value) {
+            /* the waves of the block leave together: a wave that has run dry keeps calling closest() (for its barriers) */
+            if (!__syncthreads_or(__ballot(has_work) != 0ull ? 1 : 0)) break;
+            if (__ballot(has_work) != 0ull) ++n_iter;
+        } else {
+            if (__ballot(has_work) == 0ull) break;
+            ++n_iter;
+        }
 #ifdef MIRT_ACTIVE_HIST
         {
             const uint32_t na_ = (uint32_t)__popcll(__ballot(has_work));
@@ -1748,6 +1880,18 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
         TracerF32Mx<false, LDS> tr{sc, L, w};
         render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
     }
+}
+
+/* the same for scenes of more than MIRT_LDS_RECORDS sorted slots: operands through the block-wide LDS ring */
+__global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32_mx_ring(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
+                                                                            float* __restrict__ partial, DevStats* __restrict__ stats) {
+    __shared__ MxLds L;
+    LaunchParams<float>* P = reinterpret_cast<LaunchParams<float>*>(L.params);
+    stage_params(P, cam, part, rp);
+    (void)L.fill(sc); /* materials only (the scene is not resident); ends with the block barrier */
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    TracerF32MxRing<MxLds> tr{sc, L, w};
+    render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
 }
 
 /* ---- K2b (+K3): add the chunks of a pixel in chunk order, scale by 1/spp (camera.rs:246), gamma + quantise
