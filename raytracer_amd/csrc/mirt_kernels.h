@@ -779,18 +779,22 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
 /* ---- f32, scenes that do not fit the LDS: the sphere operands through a block-wide LDS ring ----------------
  * trace_mx's streaming loop has every wave fetch every tile for itself (2 KB per tile and wave through L1/L2: 239
  * SIMD-cycles per tile against 191 for a resident scene).  Here the 16 waves of the block walk the tiles in step: the
- * operand area of the LDS (64 KB) is a ring of two chunks of MIRT_RING_TILES tiles, each wave copies two 1 KB slabs of the
+ * operand area of the LDS and the A / B areas behind it (96 KB) are a ring of two chunks of MIRT_RING_TILES tiles, each wave copies its 1 KB slabs of the
  * NEXT chunk with global_load_lds_dwordx4 (no VGPRs, lane-linear image = the operand layout) while all of them test the
  * current one, and one barrier per chunk hands the buffers over - 1/16 of the L1/L2 traffic.
  * The price is that the waves are no longer free-running: every wave of the block must make every call with the same
  * number of barriers (MIRT_RING chunks + 1, a function of the scene alone), so render_body keeps idle waves in the loop
  * until the whole block is out of work (T::LOCKSTEP), and a wave without a ray still stages and waits. */
-#define MIRT_RING_TILES 16u
+#ifndef MIRT_RING_TILES
+#define MIRT_RING_TILES 24u /* two chunks of 24 tiles = 96 KB: the operand area and the (unused, the scene is not resident) A / B areas behind it; 8 / 16 / 24 tiles: 119.5 / 116.0 / 114.0 ms on the 10 000-sphere frame */
+#endif
 template <class LDS>
 __device__ inline void trace_mx_ring(const DevScene<float>& sc, LDS& L, uint32_t w, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
                                      Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
-    static_assert(LDS::N_RECORDS * 4u >= 2u * MIRT_RING_TILES * 128u, "the operand area must hold two chunks");
-    static_assert(MIRT_F32_WAVES * 2u == MIRT_RING_TILES * 2u, "two slabs of a chunk per wave");
+    static_assert(offsetof(LDS, A) == sizeof(L.SM) && offsetof(LDS, B) == offsetof(LDS, A) + sizeof(L.A), "SM, A, B must be contiguous: the ring runs over all three");
+    static_assert((sizeof(L.SM) + sizeof(L.A) + sizeof(L.B)) / 16u >= 2u * MIRT_RING_TILES * 128u, "the ring must hold two chunks");
+    static_assert((MIRT_RING_TILES * 2u) % MIRT_F32_WAVES == 0u, "whole slabs per wave");
+    constexpr uint32_t SPW = MIRT_RING_TILES * 2u / MIRT_F32_WAVES; /* 1 KB slabs of a chunk per wave */
     best.t = INFINITY;
     best.idx = 0xFFFFFFFFu;
     const RayA<float> a_true = ray_a(ray.d);
@@ -801,10 +805,11 @@ __device__ inline void trace_mx_ring(const DevScene<float>& sc, LDS& L, uint32_t
     if (wave_live) mx_ray_operands(sc, ray, a_true, active, bx0, bx1, by0, by1);
     /* slabs 2 w and 2 w + 1 of chunk c -> ring buffer c & 1 (the host pads the operand array by a whole chunk of zeros) */
     auto stage = [&](uint32_t c) {
-        const uint4* src = sc.SM + ((size_t)c * MIRT_RING_TILES * 128u + (size_t)w * 128u + lane);
-        uint4* dst = L.SM + ((c & 1u) * MIRT_RING_TILES * 128u + w * 128u);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64), (__attribute__((address_space(3))) void*)(dst + 64), 16, 0, 0);
+        const uint4* src = sc.SM + ((size_t)c * MIRT_RING_TILES * 128u + (size_t)w * SPW * 64u + lane);
+        uint4* dst = L.SM + ((c & 1u) * MIRT_RING_TILES * 128u + w * SPW * 64u);
+#pragma unroll
+        for (uint32_t k = 0; k < SPW; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + k * 64u), (__attribute__((address_space(3))) void*)(dst + k * 64u), 16, 0, 0);
     };
     auto narrow = [&](uint32_t gbase, uint32_t cnt) {
         uint32_t k = 0, m = 0, gi = 0;
