@@ -79,6 +79,38 @@ def test_streaming_render_is_bit_identical_on_both_broad_phases():
     assert np.array_equal(bits(a), bits(b)) and np.array_equal(a8, b8)
 
 
+def test_ring_kernel_bands_passes_and_tiny_frames():
+    """Scenes beyond the LDS run render_kernel_f32_mx_ring, whose waves move through the tiles in step behind block barriers
+    and leave the loop together.  Bands of a partition, progressive passes, a frame with fewer items than one block has
+    lanes (most waves never get work) and a one-pixel frame all give the vector-ALU kernel's frame."""
+    import ctypes as C
+
+    sc = presets.stress_scene(1500, seed=11)
+    lib, ds = abi.load(), sc.device_scene(0)
+    cam = presets.stress_camera(72, 4, 10)
+    full, full8 = cam.render_arrays(sc, precision=abi.F32, seed=6)
+    seg = cam.last_stats["segments"]
+    v, v8 = cam.render_arrays(sc, precision=abi.F32, seed=6, accel="valu")
+    assert cam.last_stats["segments"] == seg and np.array_equal(bits(full), bits(v)) and np.array_equal(full8, v8)
+    acc = np.zeros_like(full)
+    for r in range(3):
+        part = np.zeros_like(full)
+        o = cam.opts(precision=abi.F32, seed=6, strip_rows=4, part_index=r, part_count=3)
+        abi.check(lib.mirt_render(ds.handle, C.byref(cam.pod), C.byref(o), part.ctypes.data, None, None))
+        acc += part
+    assert np.array_equal(bits(acc), bits(full))
+    g = cam.pass_granularity(precision=abi.F32)
+    accum = np.full(full.shape, np.nan, np.float32)
+    for a, b in ((0, g), (g, 4)) if g < 4 else ((0, 4),):
+        lin, _ = cam.render_pass(sc, a, b - a, accum, precision=abi.F32, seed=6)
+    assert np.array_equal(bits(lin), bits(full))
+    for w, spp in ((5, 1), (1, 0), (3, 7)):
+        small = presets.stress_camera(w, spp, 6)
+        a, _ = small.render_arrays(sc, precision=abi.F32, seed=2)
+        b, _ = small.render_arrays(sc, precision=abi.F32, seed=2, accel="valu")
+        assert np.array_equal(bits(a), bits(b))
+
+
 def _moving_mix(scale, n=300, seed=9):
     rng = np.random.default_rng(seed)
     sc = Scene()
