@@ -27,6 +27,25 @@
 
 namespace mirt {
 
+/* Wave priority: the broad phases (long runs of independent MFMA / VALU work) issue at priority 0, everything else - the exact
+ * tests, shading, ray generation: short dependent chains - at priority 1, so that on a SIMD whose waves are in different
+ * phases the latency-bound ones are served first and the tile loops fill what is left (bench frame 12.97 -> 12.61 ms; a
+ * raised priority around the MFMA cluster itself, or for the whole broad phase: null / +0.5 %).  s_setprio is a scalar
+ * instruction: all call sites are wave-uniform. */
+#ifndef MIRT_PHASE_PRIO
+#define MIRT_PHASE_PRIO 1
+#endif
+__device__ inline void prio_broad() {
+#if MIRT_PHASE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
+__device__ inline void prio_other() {
+#if MIRT_PHASE_PRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+}
+
 /* ---- discriminant of sphere.rs:83-90 -------------------------------------------------------------
  * double: the reference's expressions, one IEEE operation at a time (d = h*h - a*c with c = |oc|^2 - r^2).
  * float (the f32 spec of the throughput kernels): the same quantity through the perpendicular from the centre to the
@@ -405,6 +424,7 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
     uint32_t pre_tile = 0xFFFFFFFFu;
     uint32_t g = 0;
     while (g < ngroups) { /* one pass unless some lane's entry list fills up */
+        prio_broad();
         uint32_t cnt = 0;
         const uint32_t gbase = g;
         uint32_t glimit = g + 0x10000u; /* group numbers in the entries are 16 bit, relative to gbase */
@@ -461,6 +481,7 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
                 flush = __ballot(cnt >= MIRT_ENT_CAP) != 0ull; /* no room for another entry */
             }
         }
+        prio_other();
         pt.stamp(PH_BROAD);
         /* ---- narrow phase: each lane walks its own entries, exact test (sphere.rs:81-101) ---------------- */
         {
@@ -692,6 +713,7 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
     mirt_h8 pre0 = {}, pre1 = {};
     if (!RES) { pre0 = SM[lane]; pre1 = SM[64 + lane]; }
     while (t < ntiles) { /* one pass unless some lane's entry list fills up */
+        prio_broad();
         uint32_t cnt = 0;
         const uint32_t gbase = 2 * t;
         uint32_t tlimit = t + 0x8000u; /* group numbers in the entries are 16 bit, relative to gbase */
@@ -744,6 +766,7 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
             cnt += ((mx & my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
             flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull; /* no room for another tile */
         }
+        prio_other();
         pt.stamp(PH_BROAD);
         MIRT_DIAG(sc, DG_PASS, active);
         /* ---- narrow phase: as in trace_cons ---- */
