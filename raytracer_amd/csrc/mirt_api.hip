@@ -963,6 +963,19 @@ static void print_diagnostics(const DevStats& h) {
         double life = (double)h.life_sum / (double)(h.n_waves ? h.n_waves : 1) * 1e-5;
         fprintf(stderr, "[mirt phase timing] %llu waves, first start -> last end %.3f ms, mean wave lifetime %.3f ms (%.1f%% of the span)\n",
                 h.n_waves, span, life, 100.0 * life / (span > 0 ? span : 1));
+        {
+            const double nw = (double)(h.n_waves ? h.n_waves : 1);
+            const double first = (double)((~h.inv_start_max) & 0xFFFFFFFFFFull);
+            fprintf(stderr, "[mirt phase timing] mean start %.3f ms after the first wave's; mean end %.3f ms before the last wave's; mean time from 'queue empty' to the wave's end %.3f ms\n",
+                    ((double)h.start_sum / nw - first) * 1e-5, span - ((double)h.start_sum / nw - first) * 1e-5 - life, (double)h.idle_sum / nw * 1e-5);
+#ifndef MIRT_BLOCK_COUNTS
+            fprintf(stderr, "[mirt phase timing] waves ending k x 25 us before the longest-lived one (of an earlier identical launch), k = 0..38+:");
+            for (int k = 0; k < 39; ++k) fprintf(stderr, " %llu", h.diag[k]);
+            fprintf(stderr, "\n");
+#endif
+            fprintf(stderr, "[mirt phase timing] drain per wave: < 50 us %llu, < 100 %llu, < 200 %llu, < 400 %llu, < 800 %llu, longer %llu; lanes with work at 'queue empty' %.1f, iterations after it %.1f, shader cycles after it %.0f\n",
+                    h.diag[40], h.diag[41], h.diag[42], h.diag[43], h.diag[44], h.diag[45], (double)h.diag[46] / nw, (double)h.diag[47] / nw, (double)h.diag[39] / nw);
+        }
     }
 #endif
 }

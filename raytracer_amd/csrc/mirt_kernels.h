@@ -1437,6 +1437,9 @@ __device__ inline PixelMap map_pixel(uint32_t wave_global, uint32_t lane, uint32
     return p;
 }
 
+#ifdef MIRT_PHASE_TIMING
+static __device__ unsigned long long g_prev_life_max; /* longest wave lifetime any launch has seen: the yardstick of the end-time histogram */
+#endif
 struct DevStats { /* device-side counters, one atomic per wave at kernel end */
     unsigned long long segments, narrow, wave_iters, nan_pixels;
     unsigned int queue_head; /* next unclaimed work item of the running render launch */
@@ -1448,6 +1451,8 @@ struct DevStats { /* device-side counters, one atomic per wave at kernel end */
     unsigned long long end_max;         /* latest wave end */
     unsigned long long life_sum;        /* sum over waves of (end - start) */
     unsigned long long n_waves;
+    unsigned long long start_sum;       /* sum over waves of their start tick minus the launch's base tick (stats->queue time): see host */
+    unsigned long long idle_sum;        /* sum over waves of (end of the wave - its last iteration with a full complement of work): the drain */
     unsigned long long bvh_lane_steps, bvh_wave_steps, bvh_leaf_rounds, bvh_lane_leaves; /* -DMIRT_PHASE_TIMING -DMIRT_BVH_COUNTERS */
     unsigned long long diag[48]; /* -DMIRT_PHASE_TIMING: MIRT_DIAG, [k] wave-level entries of block k, [24 + k] lanes that entered it */
 };
@@ -1597,6 +1602,8 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
     pt.start();
 #ifdef MIRT_PHASE_TIMING
     const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long drain_t0 = 0; /* when this wave first found the queue empty */
+    unsigned long long drain_live = 0, drain_iters = 0, drain_c0 = 0; /* lanes with work at that moment; iterations after it */
 #endif
 
     for (;;) {
@@ -1623,6 +1630,9 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 if (lane == 0) base = atomicAdd(&stats->queue_head, batch);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= rp.n_items) {
+#ifdef MIRT_PHASE_TIMING
+                    if (!exhausted) { drain_t0 = __builtin_amdgcn_s_memrealtime(); drain_c0 = __builtin_amdgcn_s_memtime(); drain_live = (unsigned long long)__popcll(__ballot(has_work)); }
+#endif
                     exhausted = true;
                     q_next = q_end = 0;
                 } else {
@@ -1664,6 +1674,9 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 need_ray = has_work;
             }
         }
+#ifdef MIRT_PHASE_TIMING
+        if (exhausted) ++drain_iters;
+#endif
         if constexpr (tracer_lockstep<T>::value) {
             /* the waves of the block leave together: a wave that has run dry keeps calling closest() (for its barriers) */
             if (!__syncthreads_or(__ballot(has_work) != 0ull ? 1 : 0)) break;
@@ -1774,11 +1787,30 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
     }
 #ifdef MIRT_PHASE_TIMING
     if (lane == 0) {
+        const unsigned long long wave_t1 = __builtin_amdgcn_s_memrealtime(); /* before the atomics below: 4096 waves ending together queue up on them */
+        const unsigned long long wave_c1 = __builtin_amdgcn_s_memtime();
         for (int i = 0; i < 6; ++i) atomicAdd(&stats->phase_cycles[i], pt.acc[i]);
-        const unsigned long long wave_t1 = __builtin_amdgcn_s_memrealtime();
         atomicMax(&stats->inv_start_max, ~wave_t0);
         atomicMax(&stats->end_max, wave_t1);
         atomicAdd(&stats->life_sum, wave_t1 - wave_t0);
+        atomicAdd(&stats->start_sum, wave_t0 & 0xFFFFFFFFFFull);
+        atomicAdd(&stats->idle_sum, wave_t1 - drain_t0);
+        {
+            const unsigned long long d_ = wave_t1 - drain_t0; /* 100 MHz ticks: 5000 = 50 us */
+            const int b_ = d_ < 5000 ? 0 : d_ < 10000 ? 1 : d_ < 20000 ? 2 : d_ < 40000 ? 3 : d_ < 80000 ? 4 : 5;
+            atomicAdd(&stats->diag[40 + b_], 1ull);
+            atomicAdd(&stats->diag[46], drain_live);
+            atomicAdd(&stats->diag[47], drain_iters);
+            atomicAdd(&stats->diag[39], wave_c1 - drain_c0);
+#ifndef MIRT_BLOCK_COUNTS
+            { /* how long before the longest-lived wave (of the previous, identical launch) this one ended: 25 us buckets */
+                const unsigned long long life_ = wave_t1 - wave_t0, ref_ = g_prev_life_max;
+                const unsigned long long gap_ = ref_ > life_ ? ref_ - life_ : 0ull;
+                atomicAdd(&stats->diag[gap_ / 2500ull < 38ull ? gap_ / 2500ull : 38ull], 1ull);
+                atomicMax(&g_prev_life_max, life_);
+            }
+#endif
+        }
         atomicAdd(&stats->n_waves, 1ull);
     }
 #endif

@@ -7,6 +7,6 @@ out=$1; shift
 for v in phase counts; do
   [ -f variants/$v.so ] || continue
   MIRT_LIB=$PWD/variants/$v.so timeout -k 10 300 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > /dev/null 2> $out.err || { tail -5 $out.err; exit 1; }
-  if [ $v = phase ]; then grep "^\[mirt phase" $out.err | tail -2 >> $out; else grep "^\[mirt block" $out.err | awk '!seen[$0]++' | tail -24 >> $out; fi
+  if [ $v = phase ]; then grep "^\[mirt phase" $out.err | tail -3 >> $out; else grep "^\[mirt block" $out.err | awk '!seen[$0]++' | tail -24 >> $out; fi
 done
 cat $out
