@@ -34,6 +34,7 @@ def load():
     lib.oracle_primary_hits.argtypes = [P(abi.MirtSceneDesc), P(abi.MirtCamera), u32, vp, u32, vp, vp]
     lib.oracle_render.argtypes = [P(abi.MirtSceneDesc), P(abi.MirtCamera), u32, u64, vp, u32, C.c_int, u32, u32, vp, vp, P(u64)]
     lib.oracle_render_spec.argtypes = [P(abi.MirtSceneDesc), P(abi.MirtCamera), u32, u64, vp, u32, C.c_int, u32, u32, u32, vp, vp, P(u64)]
+    lib.oracle_render_ex.argtypes = [P(abi.MirtSceneDesc), P(abi.MirtCamera), u32, u32, u64, vp, u32, C.c_int, u32, u32, u32, vp, vp, P(u64), vp]
     lib.oracle_quantize.argtypes = [vp, u32, C.c_size_t, vp]
     lib.oracle_sphere_hit.argtypes = [P(abi.MirtSphere), P(dbl), P(dbl), dbl, dbl, dbl, P(dbl)]
     lib.oracle_aabb_slab.argtypes = [P(dbl), P(dbl), P(dbl), P(dbl), C.c_int, dbl, dbl]
@@ -92,6 +93,24 @@ def render(flat, cam_pod, precision=abi.F64, seed=0, use_bvh=False, threads=1, r
     else:
         nan = load().oracle_render(*common, *outs)
     return lin, rgb8, int(seg.value), nan
+
+
+def render_ex(flat, cam_pod, precision=abi.F64, draws=0, seed=0, use_bvh=False, threads=1, spec_chunk=0, want_rgb8=True):
+    """oracle_render_ex: as render(), plus `draws` = 32 with precision F64 - the reference's f64 arithmetic fed with the
+    uniforms of the f32 mode (the frame an MIRT_F32 render is held to, per pixel, in tests/test_gpu_f32_vs_reference.py) -
+    and the per-pixel path signatures.  Returns (linear, rgb8, segments, signatures)."""
+    H, W = cam_pod.img_height, cam_pod.img_width
+    lin = np.zeros((H, W, 3), _real(precision))
+    rgb8 = np.zeros((H, W, 3), np.uint8) if want_rgb8 else None
+    sig = np.zeros((H, W), np.uint64)
+    seg = C.c_uint64(0)
+    objs = flat.objects if use_bvh else None
+    rc = load().oracle_render_ex(C.byref(flat.desc), C.byref(cam_pod), precision, draws, seed, None if objs is None else objs.ctypes.data,
+                                 0 if objs is None else len(objs), threads, 0, 0, spec_chunk, lin.ctypes.data,
+                                 None if rgb8 is None else rgb8.ctypes.data, C.byref(seg), sig.ctypes.data)
+    if rc < 0:
+        raise ValueError("oracle_render_ex: unsupported precision / draws combination")
+    return lin, rgb8, int(seg.value), sig
 
 
 def quantize(lin: np.ndarray):

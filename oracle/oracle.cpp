@@ -64,10 +64,16 @@ static inline void philox4x32_10(const uint32_t c_in[4], const uint32_t k_in[2],
  *   f32: block = d / 4, 32-bit word d % 4,                              u = (word >> 8) * 2^-24
  * Blocks are computed lazily so that a draw the reference short-circuits away costs nothing here either. */
 template <class R> struct Draws;
+static inline float f32_layout_dim(uint32_t pixel, uint32_t sample, uint32_t bounce, uint64_t seed, uint32_t d);
 template <> struct Draws<double> {
     uint32_t pixel, sample, bounce;
     uint64_t seed;
+    /* f32_layout: the reference's f64 arithmetic fed with the uniforms of the f32 mode - dimension d is the binary32 value
+     * Draws<float>::dim(d) widened (exactly) to double.  This is what ties the throughput mode to the reference's own
+     * arithmetic "once the same seeded RNG stream is used" (oracle_render_ex, tests/test_gpu_f32_vs_reference.py). */
+    bool f32_layout = false;
     double dim(uint32_t d) const {
+        if (f32_layout) return (double)f32_layout_dim(pixel, sample, bounce, seed, d);
         uint32_t c[4] = {pixel, sample, bounce, d / 2};
         uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
         uint32_t o[4];
@@ -91,6 +97,16 @@ template <> struct Draws<float> {
         return (float)(o[d < 5 ? d : (d - 5) % 4] >> 8) * 0x1.0p-24f;
     }
 };
+static inline float f32_layout_dim(uint32_t pixel, uint32_t sample, uint32_t bounce, uint64_t seed, uint32_t d) {
+    return Draws<float>{pixel, sample, bounce, seed}.dim(d);
+}
+
+/* Path signature (test infrastructure, no reference counterpart): a hash of every DISCRETE decision the samples of a pixel
+ * take - which sphere each segment hits and on which face, whether the material scatters, reflect or refract, checker
+ * parity, texel index.  Two renders of one pixel whose signatures agree differ by rounding only; where they disagree some
+ * sample's path branched differently.  Thread-local, reset per pixel by render_rows. */
+static thread_local uint64_t tl_sig = 0;
+static inline void sig_mix(uint64_t v) { tl_sig = (tl_sig ^ (v + 0x9E3779B97F4A7C15ull)) * 0x100000001B3ull; }
 
 /* ------------------------------------------------------------------------------------------------
  * core/point3.rs, core/ray.rs, utils/interval.rs
@@ -468,6 +484,7 @@ template <class R> static inline V3<R> texture_color(const Scene<R>& sc, const T
             else k = (int32_t)f;
             acc = (int32_t)((uint32_t)acc + (uint32_t)k);
         }
+        sig_mix(0x300u + (uint32_t)(acc % 2 == 0));
         return (acc % 2 == 0) ? t.even : t.odd;
     }
     default: { /* IMAGE texture.rs:71-94 */
@@ -487,6 +504,8 @@ template <class R> static inline V3<R> texture_color(const Scene<R>& sc, const T
         v = clamp01(std::fabs(v));
         uint32_t i = std::min(as_u32(u * (R)im.w), im.w - 1);
         uint32_t j = std::min(as_u32(v * (R)im.h), im.h - 1);
+        sig_mix(0x400u);
+        sig_mix(((uint64_t)j << 32) | i);
         const uint8_t* px = &im.rgb[((size_t)j * im.w + i) * 3];
         if constexpr (sizeof(R) == 8) return {(R)px[0] / (R)255.0, (R)px[1] / (R)255.0, (R)px[2] / (R)255.0};
         else return {(R)px[0], (R)px[1], (R)px[2]}; /* f32 spec: bytes here, one product with (1/255)/reflectance in scatter() */
@@ -522,6 +541,7 @@ static inline bool scatter(const Scene<R>& sc, const Material<R>& m, const Ray<R
     switch (m.kind) {
     case MIRT_MAT_LAMBERTIAN: { /* material.rs:59-84 */
         R ua = dr.dim(0);
+        sig_mix(0x100u + (uint32_t)(ua < m.reflectance));
         if (ua < m.reflectance) {
             R ub = dr.dim(1), uc = dr.dim(2), ud = dr.dim(3);
             V3<R> dir = hr.n + random_unit_on_sphere(ub, uc, ud);
@@ -543,6 +563,7 @@ static inline bool scatter(const Scene<R>& sc, const Material<R>& m, const Ray<R
         }
         out = {hr.p, refl, rin.tm};
         att = m.albedo;
+        sig_mix(0x110u + (uint32_t)(!m.has_fuzz || dot(out.d, hr.n) > (R)0.0));
         return !m.has_fuzz || dot(out.d, hr.n) > (R)0.0;
     }
     default: { /* DIELECTRIC material.rs:126-154 */
@@ -556,6 +577,7 @@ static inline bool scatter(const Scene<R>& sc, const Material<R>& m, const Ray<R
             R ua = dr.dim(0);
             refl = schlick(cos_theta, ri) > ua;
         }
+        sig_mix(0x120u + (uint32_t)refl);
         V3<R> dir = refl ? reflect(ud, hr.n) : refract(ud, hr.n, ri);
         out = {hr.p, dir, rin.tm};
         return true;
@@ -587,6 +609,7 @@ static V3<R> color(const Scene<R>& sc, const Ray<R>& ray, uint32_t depth, Draws<
     if (sc.hit(ray, Interval<R>{(R)0.001, std::numeric_limits<R>::infinity()}, rec, use_bvh)) {
         V3<R> att{(R)0.0, (R)0.0, (R)0.0};
         Ray<R> sca{};
+        sig_mix(((uint64_t)rec.id << 1) | (uint64_t)rec.front);
         dr.bounce += 1;
         if (scatter(sc, sc.mats[sc.spheres[rec.id].mat], ray, rec, dr, att, sca)) {
             V3<R> c = color(sc, sca, depth - 1, dr, use_bvh);
@@ -594,6 +617,7 @@ static V3<R> color(const Scene<R>& sc, const Ray<R>& ray, uint32_t depth, Draws<
         }
         return {(R)0.0, (R)0.0, (R)0.0};
     }
+    sig_mix(0x7FFFFFFFFull); /* miss */
     V3<R> ud = unit(ray.d);
     R a = (R)0.5 * (ud.y + (R)1.0);
     /* ARgb(1,1,1)*(1-a) + ARgb(0.5,0.7,1.0)*a */
@@ -615,12 +639,14 @@ static V3<R> color_running_product(const Scene<R>& sc, Ray<R> ray, uint32_t dept
         if (!sc.hit(ray, Interval<R>{(R)0.001, std::numeric_limits<R>::infinity()}, rec, use_bvh)) break;
         V3<R> att{(R)0.0, (R)0.0, (R)0.0};
         Ray<R> sca{};
+        sig_mix(((uint64_t)rec.id << 1) | (uint64_t)rec.front);
         dr.bounce += 1;
         if (!scatter(sc, sc.mats[sc.spheres[rec.id].mat], ray, rec, dr, att, sca)) return {(R)0.0, (R)0.0, (R)0.0};
         thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
         ray = sca;
         --depth;
     }
+    sig_mix(0x7FFFFFFFFull); /* miss */
     V3<R> ud = unit(ray.d);
     R a = (R)0.5 * (ud.y + (R)1.0);
     V3<R> sky = {(R)1.0 * ((R)1.0 - a) + (R)0.5 * a, (R)1.0 * ((R)1.0 - a) + (R)0.7 * a, (R)1.0 * ((R)1.0 - a) + (R)1.0 * a};
@@ -685,21 +711,35 @@ template <class R> static inline bool quantize(R x, uint8_t& out) {
 /* spec_chunk == 0: the reference's pixel arithmetic (camera.rs:241-246, recursion order of camera.rs:277).
  * spec_chunk == Q > 0: the throughput kernels' - running product per path, and the pixel as the sum, in chunk order, of the
  * sums of Q consecutive samples (a work item of the HIP kernel; Q = mirt_pass_granularity). */
+template <class R> static inline Draws<R> make_draws(uint32_t pix, uint32_t s, uint64_t seed, bool f32_layout);
+template <> inline Draws<double> make_draws<double>(uint32_t pix, uint32_t s, uint64_t seed, bool f32_layout) {
+    Draws<double> d{pix, s, 0, seed};
+    d.f32_layout = f32_layout;
+    return d;
+}
+template <> inline Draws<float> make_draws<float>(uint32_t pix, uint32_t s, uint64_t seed, bool) { return Draws<float>{pix, s, 0, seed}; }
+
+struct Extra { /* oracle_render_ex: uniforms of the f32 layout in the f64 instantiation; per-pixel path signatures */
+    bool f32_layout = false;
+    uint64_t* sig = nullptr;
+};
+
 template <class R>
 static int render_rows(const Scene<R>& sc, const Cam<R>& cam, uint64_t seed, bool use_bvh, uint32_t row0, uint32_t row1, R* lin,
-                       uint8_t* rgb8, uint32_t spec_chunk = 0) {
+                       uint8_t* rgb8, uint32_t spec_chunk = 0, Extra ex = Extra()) {
     int nan = 0;
     const uint64_t seg0 = tl_segments;
     for (uint32_t hn = row0; hn < row1; ++hn)
         for (uint32_t wn = 0; wn < cam.W; ++wn) {
             V3<R> px{(R)0.0, (R)0.0, (R)0.0};
             uint32_t pix = hn * cam.W + wn;
+            tl_sig = 0;
             if (spec_chunk > 0) {
                 const uint32_t ns = cam.spp > 0 ? cam.spp : 1u;
                 for (uint32_t s0 = 0; s0 < ns; s0 += spec_chunk) {
                     V3<R> item{(R)0.0, (R)0.0, (R)0.0};
                     for (uint32_t s = s0; s < s0 + spec_chunk && s < ns; ++s) {
-                        Draws<R> dr{pix, s, 0, seed};
+                        Draws<R> dr = make_draws<R>(pix, s, seed, ex.f32_layout);
                         Ray<R> r = cam.spp > 0 ? ray_for(cam, wn, hn, dr) : primary_ray(cam, wn, hn);
                         item = item + color_running_product(sc, r, cam.depth, dr, use_bvh);
                     }
@@ -708,16 +748,17 @@ static int render_rows(const Scene<R>& sc, const Cam<R>& cam, uint64_t seed, boo
                 if (cam.spp > 0) px = px * ((R)1.0 / (R)cam.spp);
             } else if (cam.spp > 0) { /* camera.rs:241-246 */
                 for (uint32_t s = 0; s < cam.spp; ++s) {
-                    Draws<R> dr{pix, s, 0, seed};
+                    Draws<R> dr = make_draws<R>(pix, s, seed, ex.f32_layout);
                     Ray<R> r = ray_for(cam, wn, hn, dr);
                     px = px + color(sc, r, cam.depth, dr, use_bvh);
                 }
                 px = px * ((R)1.0 / (R)cam.spp);
             } else { /* camera.rs:247-254 */
-                Draws<R> dr{pix, 0, 0, seed};
+                Draws<R> dr = make_draws<R>(pix, 0, seed, ex.f32_layout);
                 px = color(sc, primary_ray(cam, wn, hn), cam.depth, dr, use_bvh);
             }
             size_t o = (size_t)pix * 3;
+            if (ex.sig) ex.sig[pix] = tl_sig;
             if (lin) { lin[o] = px.x; lin[o + 1] = px.y; lin[o + 2] = px.z; }
             if (rgb8) {
                 if (!quantize(px.x, rgb8[o])) ++nan;
@@ -731,7 +772,8 @@ static int render_rows(const Scene<R>& sc, const Cam<R>& cam, uint64_t seed, boo
 
 template <class R>
 static int render_t(const mirt_scene_desc* d, const mirt_camera* c, uint64_t seed, const uint32_t* objects, uint32_t n_objects,
-                    int threads, uint32_t row_begin, uint32_t row_end, void* lin_v, uint8_t* rgb8, uint64_t* segments, uint32_t spec_chunk = 0) {
+                    int threads, uint32_t row_begin, uint32_t row_end, void* lin_v, uint8_t* rgb8, uint64_t* segments, uint32_t spec_chunk = 0,
+                    Extra ex = Extra()) {
     Scene<R> sc;
     sc.load(d);
     bool use_bvh = objects != nullptr && n_objects > 0;
@@ -741,7 +783,7 @@ static int render_t(const mirt_scene_desc* d, const mirt_camera* c, uint64_t see
     R* lin = (R*)lin_v;
     std::atomic<int> nan{0};
     if (threads <= 1) {
-        nan = render_rows(sc, cam, seed, use_bvh, row_begin, row_end, lin, rgb8, spec_chunk);
+        nan = render_rows(sc, cam, seed, use_bvh, row_begin, row_end, lin, rgb8, spec_chunk, ex);
     } else {
         std::atomic<uint32_t> next{row_begin};
         std::vector<std::thread> pool;
@@ -750,7 +792,7 @@ static int render_t(const mirt_scene_desc* d, const mirt_camera* c, uint64_t see
                 for (;;) {
                     uint32_t r = next.fetch_add(1);
                     if (r >= row_end) break;
-                    nan += render_rows(sc, cam, seed, use_bvh, r, r + 1, lin, rgb8, spec_chunk);
+                    nan += render_rows(sc, cam, seed, use_bvh, r, r + 1, lin, rgb8, spec_chunk, ex);
                 }
             });
         for (auto& t : pool) t.join();
@@ -864,6 +906,26 @@ int oracle_render_spec(const mirt_scene_desc* d, const mirt_camera* c, uint32_t 
     if (chunk == 0) chunk = 1;
     if (precision == 64) return orc::render_t<double>(d, c, seed, objects, n_objects, threads, row_begin, row_end, rgb_linear, rgb8, segments, chunk);
     return orc::render_t<float>(d, c, seed, objects, n_objects, threads, row_begin, row_end, rgb_linear, rgb8, segments, chunk);
+}
+
+/* The general form.  precision 64 + draws 32: THE REFERENCE'S ARITHMETIC ON THE THROUGHPUT MODE'S RANDOM NUMBERS - Real = double,
+ * every operation and its order as the Rust source has them (color()'s recursion, the textbook discriminant of
+ * sphere.rs:83-90, true divisions, libm's tan/acos/atan2/sin/cos, the BVH walk when `objects` is given), with each uniform
+ * the binary32 value the f32 mode draws for the same (pixel, sample, bounce, dimension), widened to double.  An f32 frame of
+ * the HIP kernels compared with THIS frame differs by the rounding of binary32 arithmetic and by the f32 spec's own
+ * departures only - not by Monte-Carlo noise.  draws 0 = the precision's own layout.  chunk 0 = reference
+ * pixel arithmetic, Q >= 1 = the f32 spec's (render_rows).  sig (may be NULL): W*H path signatures (sig_mix). */
+int oracle_render_ex(const mirt_scene_desc* d, const mirt_camera* c, uint32_t precision, uint32_t draws, uint64_t seed,
+                     const uint32_t* objects, uint32_t n_objects, int threads, uint32_t row_begin, uint32_t row_end, uint32_t chunk,
+                     void* rgb_linear, uint8_t* rgb8, uint64_t* segments, uint64_t* sig) {
+    orc::Extra ex;
+    ex.sig = sig;
+    if (precision == 64) {
+        ex.f32_layout = draws == 32;
+        return orc::render_t<double>(d, c, seed, objects, n_objects, threads, row_begin, row_end, rgb_linear, rgb8, segments, chunk, ex);
+    }
+    if (draws == 64) return -1; /* binary32 arithmetic on 53-bit uniforms: not a mode anything here needs */
+    return orc::render_t<float>(d, c, seed, objects, n_objects, threads, row_begin, row_end, rgb_linear, rgb8, segments, chunk, ex);
 }
 
 int oracle_quantize(const void* lin, uint32_t precision, size_t n, uint8_t* out) {

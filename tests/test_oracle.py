@@ -406,3 +406,55 @@ def test_f32_spec_paths_are_as_long_as_f64_paths_from_a_far_camera():
         _, _, seg[prec], nan = ob.render(sc.flat, cam.pod, precision=prec, seed=1, use_bvh=True, threads=8, want_rgb8=False, spec_chunk=chunk)
         assert nan == 0
     assert abs(seg[abi.F32] - seg[abi.F64]) < 0.02 * seg[abi.F64], seg
+
+
+# ---- the f32 spec against the reference's arithmetic under the same uniforms ---------------------------
+def test_f32_layout_draws_in_the_f64_instantiation(oracle):
+    """oracle_render_ex(precision 64, draws 32) feeds Real = double with the binary32 uniforms of the f32 layout: on a scene
+    with nothing to hit the frame is a pure function of the two anti-aliasing draws, so it can be recomputed here."""
+    cam = presets.plain_camera(8, 3, 5)
+    sc = Scene()
+    sc.add(Sphere.new_static(0.5, (0.0, 0.0, 50.0), Lambertian.new((0.5, 0.5, 0.5), 1.0)))  # behind the camera
+    sc.build_bvh()
+    lin, _, seg, sig = oracle.render_ex(sc.flat, cam.pod, abi.F64, 32, 7, use_bvh=True)
+    assert seg == cam.width * cam.height * 3 and len(np.unique(sig)) == 1
+    p = cam.pod
+    for (hn, wn) in ((0, 0), (3, 5)):
+        acc = np.zeros(3)
+        for s in range(3):
+            ox = oracle.draw_dim(7, hn * cam.width + wn, s, 0, 0, abi.F32) - 0.5
+            oy = oracle.draw_dim(7, hn * cam.width + wn, s, 0, 1, abi.F32) - 0.5
+            d = [p.px00_loc[i] + p.px_du[i] * (wn + ox) + p.px_dv[i] * (hn + oy) - p.lookfrom[i] for i in range(3)]
+            a = 0.5 * (d[1] / math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + 1.0)
+            acc += np.array([1.0 * (1.0 - a) + 0.5 * a, 1.0 * (1.0 - a) + 0.7 * a, 1.0 * (1.0 - a) + 1.0 * a])
+        assert np.array_equal(lin[hn, wn], acc * (1.0 / 3.0))
+    # the f64 layout gives another frame; binary32 arithmetic on 53-bit uniforms is refused
+    lin64, _, _, _ = oracle.render_ex(sc.flat, cam.pod, abi.F64, 0, 7, use_bvh=True)
+    assert not np.array_equal(lin, lin64)
+    with pytest.raises(ValueError):
+        oracle.render_ex(sc.flat, cam.pod, abi.F32, 64, 7)
+
+
+def test_path_signatures_tell_branches_from_rounding(oracle):
+    """Equal frames have equal signatures; BVH walk and brute force take the same discrete paths; another seed does not."""
+    sc, cam = presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(48, 3, 20)
+    a = oracle.render_ex(sc.flat, cam.pod, abi.F64, 32, 5, use_bvh=True, threads=4)
+    b = oracle.render_ex(sc.flat, cam.pod, abi.F64, 32, 5, use_bvh=False, threads=2)
+    c = oracle.render_ex(sc.flat, cam.pod, abi.F64, 32, 6, use_bvh=True, threads=4)
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[0], b[0])
+    assert (a[3] != c[3]).mean() > 0.5  # the sky rows take the same one-segment path under any seed
+    # signatures ride along: the frame is render()'s
+    lin, _, seg, _ = oracle.render(sc.flat, cam.pod, abi.F32, seed=5, threads=4, spec_chunk=2)
+    e = oracle.render_ex(sc.flat, cam.pod, abi.F32, 0, 5, threads=4, spec_chunk=2)
+    assert np.array_equal(lin.view(np.uint32), e[0].view(np.uint32)) and seg == e[2]
+
+
+@pytest.mark.parametrize("name", ["c1", "bench", "textured", "stress"])
+def test_f32_spec_against_reference_arithmetic_same_uniforms(name):
+    """The f32 SPEC (which the HIP kernels reproduce bit for bit, tests/test_gpu_exact.py) within the stated bars of the
+    reference's f64 arithmetic fed with the same uniforms - the CPU half of tests/test_gpu_f32_vs_reference.py, so that a change
+    of the f32 spec that biases the image fails here before it reaches a GPU."""
+    from tools import f32_vs_reference as fr
+
+    st = fr.run(name)
+    assert not fr.failures(st, fr.BARS[name]), (fr.failures(st, fr.BARS[name]), st)
