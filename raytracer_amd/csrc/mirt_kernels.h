@@ -118,15 +118,35 @@ template <class R> struct GeomGlobal {
     __device__ inline uint32_t material(uint32_t i) const { return sc.material[i]; }
 };
 
+struct DevStats { /* device-side counters, one atomic per wave at kernel end */
+    unsigned long long segments, narrow, wave_iters, nan_pixels;
+    unsigned int queue_head; /* next unclaimed work item of the running render launch */
+    unsigned int _pad;
+    unsigned long long phase_cycles[6]; /* diagnostic builds only (MIRT_PHASE_TIMING) */
+    unsigned long long broad_misses;    /* diagnostic builds only (MIRT_VERIFY_BROAD): must be 0 */
+    /* diagnostic builds only (MIRT_PHASE_TIMING), in s_memrealtime ticks (100 MHz): */
+    unsigned long long inv_start_max;   /* ~(earliest wave start) */
+    unsigned long long end_max;         /* latest wave end */
+    unsigned long long life_sum;        /* sum over waves of (end - start) */
+    unsigned long long n_waves;
+    unsigned long long start_sum;       /* sum over waves of their start tick minus the launch's base tick (stats->queue time): see host */
+    unsigned long long idle_sum;        /* sum over waves of (end of the wave - its last iteration with a full complement of work): the drain */
+    unsigned long long bvh_lane_steps, bvh_wave_steps, bvh_leaf_rounds, bvh_lane_leaves; /* -DMIRT_PHASE_TIMING -DMIRT_BVH_COUNTERS */
+    unsigned long long diag[48]; /* -DMIRT_PHASE_TIMING: MIRT_DIAG, [k] wave-level entries of block k, [24 + k] lanes that entered it */
+};
+
 /* Diagnostic build only (-DMIRT_PHASE_TIMING -DMIRT_BLOCK_COUNTS): wave-level execution counts of the divergent blocks of the segment loop
  * (DevStats::diag[k] += 1 whenever at least one lane of a wave enters block k); printed by the host next to the phase cycles. */
+/* sc.dbg points at DevStats::broad_misses; diag[] sits this many 64-bit words behind it (round 2 added two fields in between and left
+ * the constant at 9: every label of profiles/r02_*_phase_split.txt printed after that is two rows off) */
+#define MIRT_DIAG_BASE ((offsetof(DevStats, diag) - offsetof(DevStats, broad_misses)) / 8)
 #ifdef MIRT_BLOCK_COUNTS /* a build of its own (with -DMIRT_PHASE_TIMING for the printing): the atomics distort the cycle split */
 #define MIRT_DIAG(sc, k, cond)                                                                                   \
     do {                                                                                                         \
         const unsigned long long b_ = __ballot(cond);                                                            \
         if (b_ != 0ull && (cond) && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)b_) - 1)) {             \
-            atomicAdd((unsigned long long*)(sc).dbg + 9 + (k), 1ull);                                            \
-            atomicAdd((unsigned long long*)(sc).dbg + 9 + 24 + (k), (unsigned long long)__popcll(b_));           \
+            atomicAdd((unsigned long long*)(sc).dbg + MIRT_DIAG_BASE + (k), 1ull);                               \
+            atomicAdd((unsigned long long*)(sc).dbg + MIRT_DIAG_BASE + 24 + (k), (unsigned long long)__popcll(b_)); \
         }                                                                                                        \
     } while (0)
 #else
@@ -561,19 +581,28 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
 typedef _Float16 mirt_h8 __attribute__((ext_vector_type(8)));
 typedef float mirt_f16v __attribute__((ext_vector_type(16)));
 typedef uint32_t mirt_u4 __attribute__((ext_vector_type(4)));
-/* Two layouts of the 160 KB: scenes of up to 512 sorted slots (the bench scene) keep 640 material records beside their
+/* Two layouts of the 160 KB: scenes of up to 512 sorted slots (the bench scene) keep 512 material records (one per sphere at most, unless the description carries unused ones) beside their
  * operands; up to 1024 slots the operands take twice the room and the materials get what is left. */
-template <uint32_t RECORDS, uint32_t MATS, uint32_t ENT_WORDS = 12> struct MxLdsT {
+template <uint32_t RECORDS, uint32_t MATS, uint32_t ENT_WORDS = 12, uint32_t PAIRS = 0> struct MxLdsT {
     static constexpr bool GEOM_LDS = true; /* exact records and material ids of a resident scene are here as well */
     static constexpr uint32_t N_RECORDS = RECORDS, N_MATS = MATS;
+    /* PAIRS > 0: the narrow phase of a resident scene is balanced across the lanes of the wave (narrow_balanced): a ring of
+     * PAIRS (ray lane, sphere) pairs per wave, one (t, hit id, sphere) result slot per lane, the hit ids of the sorted slots */
+    static constexpr uint32_t PAIR_CAP = PAIRS;
+    static_assert(PAIRS == 0 || (PAIRS >= 128 && (PAIRS & (PAIRS - 1)) == 0 && RECORDS <= 1024), "pair ring: a power of two >= 128; 10-bit sphere index");
     uint4 SM[RECORDS * 4]; /* 2 x 64 x 16 B per tile of 32 spheres */
     float4 A[RECORDS];
     float4 B[RECORDS];
+    unsigned long long slot[PAIRS ? MIRT_F32_WAVES : 1][PAIRS ? MIRT_WAVE : 1];
+    uint16_t pairs[PAIRS ? MIRT_F32_WAVES : 1][PAIRS ? PAIRS : 1];
+    uint16_t oid[PAIRS ? RECORDS : 1];
     uint16_t mat[RECORDS];
     static constexpr uint32_t LDS_ENT_CAP = ENT_WORDS; /* in 4-byte words: trace_mx stores ENT_WORDS / 2 tile entries of 8 bytes */
-    uint32_t ent[MIRT_F32_WAVES][LDS_ENT_CAP][MIRT_WAVE];
-    DevMaterial<float> mats[MATS]; /* the scene's materials when they fit: the shading of a segment starts with this record */
-    uint32_t params[120]; /* the block's copy of camera, partition and launch parameters (render_kernel_f32_mx) */
+    /* 16-byte alignment spelled out: trace_mx writes 8-byte entries and stage_params 16-byte words; with the lists at a 4-byte
+     * offset the compiler splits every entry access in two and the bench frame takes 13.5 ms instead of 12.5 */
+    alignas(16) uint32_t ent[MIRT_F32_WAVES][LDS_ENT_CAP][MIRT_WAVE];
+    alignas(16) DevMaterial<float> mats[MATS]; /* the scene's materials when they fit: the shading of a segment starts with this record */
+    alignas(16) uint32_t params[120]; /* the block's copy of camera, partition and launch parameters (render_kernel_f32_mx) */
     /* all threads of the block; true when the scene is resident (larger scenes read their operands through L1/L2) */
     __device__ inline bool fill(const DevScene<float>& sc) {
         const bool res = sc.n <= RECORDS && sc.n_materials <= 0x10000u;
@@ -590,6 +619,7 @@ template <uint32_t RECORDS, uint32_t MATS, uint32_t ENT_WORDS = 12> struct MxLds
                 A[i] = sc.A[i];
                 B[i] = sc.B[i];
                 mat[i] = (uint16_t)sc.material[i];
+                if (PAIRS) oid[i] = (uint16_t)sc.orig_id[i]; /* < RECORDS real spheres: the ids fit (a dummy's 0xFFFF never wins) */
             }
         }
         __syncthreads();
@@ -600,7 +630,10 @@ template <uint32_t RECORDS, uint32_t MATS, uint32_t ENT_WORDS = 12> struct MxLds
 #ifndef MIRT_MX_SMALL_ENT
 #define MIRT_MX_SMALL_ENT 14
 #endif
-typedef MxLdsT<MIRT_MX_SMALL_RECORDS, 640u, MIRT_MX_SMALL_ENT> MxLdsSmall; /* 32 + 8 + 8 + 1 + 56 + 45 KB; 7 entries per lane: 13.58 -> 13.53 ms against 6 */
+#ifndef MIRT_MX_PAIRS
+#define MIRT_MX_PAIRS 128 /* 0: every lane walks its own candidates (the narrow phase of rounds 1 and 2) */
+#endif
+typedef MxLdsT<MIRT_MX_SMALL_RECORDS, 512u, MIRT_MX_SMALL_ENT, MIRT_MX_PAIRS> MxLdsSmall; /* 32 + 8 + 8 + (8 + 4 + 1) + 1 + 56 + 36 KB; 7 entries per lane: 13.58 -> 13.53 ms against 6 */
 typedef MxLdsT<MIRT_LDS_RECORDS, 184u> MxLds;            /* 64 + 16 + 16 + 2 + 48 + 12.9 KB */
 static_assert(sizeof(MxLds) <= 160u * 1024u && sizeof(MxLdsSmall) <= 160u * 1024u, "MxLds layouts must fit the CU's LDS");
 /* f64 kernels (256-thread blocks): only the operands and the entry lists; the exact f64 records come through L2 */
@@ -689,6 +722,118 @@ __device__ inline void mx_ray_operands(const DevScene<R>& sc, const RayT<R>& ray
         bx1 = __builtin_bit_cast(mirt_h8, x1); by1 = __builtin_bit_cast(mirt_h8, y1);
 }
 
+/* ---- the narrow phase balanced across the lanes of a wave (f32, resident scenes, LDS layouts with a pair ring) --------
+ * After a broad phase every lane holds its own short list of candidates - 2.4 per lane and segment on the bench frame, but
+ * unevenly: a wave ran 7.1 rounds of the exact test with a third of its lanes busy.  Here the candidates of all 64 rays go
+ * through ONE ring of (ray lane, sphere) pairs per wave in LDS, every lane takes a pair - whoever's ray it belongs to,
+ * fetching that ray from its owner's registers with ds_bpermute - and a round of exact tests is full as long as 64 pairs
+ * are waiting.  A pair's result goes back to the ray's owner through a 64-bit ds_min on the owner's slot.
+ *
+ * Why the result is the same bit for bit.  narrow_test walks a ray's candidates in list order against a shrinking
+ * interval: sphere i contributes t_i = its near root if tmin < near root, else its far root if tmin < far root (a root
+ * beyond the best so far is rejected either way: far >= near), and the best is the minimum of (t_i, hit id) in
+ * lexicographic order (strict <, exact ties to the lower hit id).  That minimum does not depend on the order of the
+ * candidates, and (t bits, hit id, sorted index) packed into 64 bits orders the same way (t > tmin > 0: positive floats
+ * order like their bit patterns), so an unordered ds_min_u64 per pair computes it.  Every t_i is evaluated by the same
+ * instructions on the same inputs as before (the fetched ray is the owner's, bit for bit). */
+template <class LDS, class = void> struct mx_pair_cap { static constexpr uint32_t value = 0; };
+template <class LDS> struct mx_pair_cap<LDS, decltype((void)LDS::PAIR_CAP)> { static constexpr uint32_t value = LDS::PAIR_CAP; };
+#define MIRT_KEY_NONE 0x7F800000FFFFFFFFull /* t = +inf, no sphere */
+__device__ inline uint32_t wave_scan_incl(uint32_t x) { /* inclusive prefix sum over the 64 lanes (checked on the hardware by bench/imul_rate.hip) */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false); /* row_shr:1 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false); /* row_shr:2 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false); /* row_shr:4 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false); /* row_shr:8 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false); /* row_bcast:15 -> rows 1, 3 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false); /* row_bcast:31 -> rows 2, 3 */
+    return x;
+}
+/* one (ray, sphere) pair: sphere.rs:81-101 against (tmin, +inf); MIRT_KEY_NONE when the sphere contributes no root */
+template <class G>
+__device__ inline unsigned long long pair_key(const DevScene<float>& sc, const G& geo, uint32_t i, uint32_t oid, const RayT<float>& ray, RayA<float> ra, float tmin) {
+    const float4 sa = geo.a(i);
+    V3<float> C = {sa.x, sa.y, sa.z};
+    if (i >= sc.n_static) {
+        const float4 sb = geo.b(i);
+        C = center_at(C, V3<float>{sb.x, sb.y, sb.z}, ray.tm);
+    }
+    const V3<float> oc = C - ray.o;
+    float h, d;
+    disc(oc, ray.d, ra, sa.w, h, d);
+    unsigned long long key = MIRT_KEY_NONE;
+    /* the same shortcuts as narrow_test: they reject only what the root test would reject */
+    if (d >= 0.0f && !(h < -h_normal_min(h) && d <= h * h && tmin >= 0.0f)) {
+        const float sq = m_sqrt(d);
+        float t = root_over_a(h - sq, ra);
+        bool ok = tmin < t && t < INFINITY;
+        if (!ok) {
+            t = root_over_a(h + sq, ra);
+            ok = tmin < t && t < INFINITY;
+        }
+        if (ok) key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((oid << 16) | i);
+    }
+    return key;
+}
+/* one round: lanes [0, count) take the pairs at ring positions head, head + 1, ... */
+template <class LDS>
+__device__ inline void narrow_round(const DevScene<float>& sc, LDS& L, uint32_t w, uint32_t lane, uint32_t head, uint32_t count, const RayT<float>& ray,
+                                    RayA<float> ra, float tmin) {
+    const bool valid = lane < count;
+    uint32_t pr = lane << 10;
+    if (valid) pr = L.pairs[w][(head + lane) & (LDS::PAIR_CAP - 1u)];
+    const uint32_t r = pr >> 10, i = pr & 1023u;
+    /* the ray of lane r, from its owner's registers (all lanes take part: a lane outside exec would hand out zeros) */
+    const int ba = (int)(r << 2);
+    auto get = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(ba, __float_as_int(v))); };
+    const RayT<float> q = {{get(ray.o.x), get(ray.o.y), get(ray.o.z)}, {get(ray.d.x), get(ray.d.y), get(ray.d.z)}, get(ray.tm)};
+    const RayA<float> qa = {get(ra.a), get(ra.inv)};
+    MIRT_DIAG(sc, DG_NARROW_ROUND, valid);
+    if (valid) {
+        const unsigned long long key = pair_key(sc, GeomLdsT<LDS>{L}, i, (uint32_t)L.oid[i], q, qa, tmin);
+        if (key != MIRT_KEY_NONE) (void)__hip_atomic_fetch_min(&L.slot[w][r], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+}
+/* the candidates of one pass of the broad phase (entry lists ent2[0 .. cnt) of every lane) -> pairs -> rounds.  head / tail
+ * are wave-uniform ring counters; whatever is left in the ring when the last pass is through is run by narrow_drain. */
+template <class LDS>
+__device__ inline void narrow_balanced(const DevScene<float>& sc, LDS& L, uint32_t w, uint32_t lane, uint2 (*ent2)[MIRT_WAVE], uint32_t gbase, uint32_t cnt,
+                                       const RayT<float>& ray, RayA<float> ra, float tmin, uint32_t& head, uint32_t& tail, uint32_t& narrow_count) {
+    uint32_t k = 0, m = 0, gi = 0;
+    for (;;) {
+        if (m == 0 && k < cnt) {
+            const uint2 e = ent2[k][lane];
+            ++k;
+            m = (~e.x & 0xFFFFu) | (~e.y << 16);
+            gi = (gbase + (e.x >> 16)) * MIRT_CGROUP + (MIRT_CGROUP - 1);
+        }
+        const unsigned long long have = __ballot(m != 0);
+        if (have == 0ull) break;
+        const uint32_t n = (uint32_t)__popcll(have);
+        if (tail - head + n > LDS::PAIR_CAP) { /* no room for this batch: a full round first (>= 64 are waiting: PAIR_CAP >= 128) */
+            narrow_round(sc, L, w, lane, head, 64u, ray, ra, tmin);
+            head += 64u;
+        }
+        if (m != 0) {
+            const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
+            m &= m - 1u;
+            const uint32_t idx = gi - bit + (bit >= 16u ? 32u : 0u);
+            const uint32_t pos = tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0u));
+            L.pairs[w][pos & (LDS::PAIR_CAP - 1u)] = (uint16_t)((lane << 10) | idx);
+            ++narrow_count;
+        }
+        tail += n;
+    }
+}
+template <class LDS>
+__device__ inline void narrow_drain(const DevScene<float>& sc, LDS& L, uint32_t w, uint32_t lane, const RayT<float>& ray, RayA<float> ra, float tmin,
+                                    uint32_t& head, uint32_t tail) {
+    while (head != tail) {
+        const uint32_t c = tail - head < 64u ? tail - head : 64u;
+        narrow_round(sc, L, w, lane, head, c, ray, ra, tmin);
+        head += c;
+    }
+}
+
 /* R = double (the parity-mode kernels): the same filter on the ray rounded to f32 - Dn is normalised in double first, so
  * direction and origin are each off by <= 2^-24 relatively, the f32 line passes within 5 eps (|M| + |O|) of the f64 one,
  * and 6 eps ((|M|+|O|)^2 + rho^2) replaces the 32 eps of the f32 derivation (an f64 discriminant needs ~1e-15) inside the
@@ -712,6 +857,9 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
     uint32_t t = 0;
     mirt_h8 pre0 = {}, pre1 = {};
     if (!RES) { pre0 = SM[lane]; pre1 = SM[64 + lane]; }
+    constexpr bool BALANCED = RES && sizeof(R) == 4 && mx_pair_cap<LDS>::value > 0;
+    uint32_t ring_head = 0, ring_tail = 0;
+    if constexpr (BALANCED) L.slot[w][lane] = MIRT_KEY_NONE;
     while (t < ntiles) { /* one pass unless some lane's entry list fills up */
         prio_broad();
         uint32_t cnt = 0;
@@ -769,6 +917,18 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
         prio_other();
         pt.stamp(PH_BROAD);
         MIRT_DIAG(sc, DG_PASS, active);
+        if constexpr (BALANCED) {
+            narrow_balanced(sc, L, w, lane, ent2, gbase, cnt, ray, a_true, tmin, ring_head, ring_tail, narrow_count);
+            if (t >= ntiles) { /* the last pass: run what is left and collect this lane's result */
+                narrow_drain(sc, L, w, lane, ray, a_true, tmin, ring_head, ring_tail);
+                const unsigned long long ks = L.slot[w][lane];
+                if (ks != MIRT_KEY_NONE) {
+                    best.t = __uint_as_float((uint32_t)(ks >> 32));
+                    best.idx = (uint32_t)ks & 0xFFFFu;
+                }
+            }
+            pt.stamp(PH_NARROW);
+        } else
         /* ---- narrow phase: as in trace_cons ---- */
         {
             uint32_t k = 0, m = 0, gi = 0;
@@ -794,8 +954,8 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
                     ++narrow_count;
                 }
             }
+            pt.stamp(PH_NARROW);
         }
-        pt.stamp(PH_NARROW);
     }
 }
 
@@ -1440,22 +1600,6 @@ __device__ inline PixelMap map_pixel(uint32_t wave_global, uint32_t lane, uint32
 #ifdef MIRT_PHASE_TIMING
 static __device__ unsigned long long g_prev_life_max; /* longest wave lifetime any launch has seen: the yardstick of the end-time histogram */
 #endif
-struct DevStats { /* device-side counters, one atomic per wave at kernel end */
-    unsigned long long segments, narrow, wave_iters, nan_pixels;
-    unsigned int queue_head; /* next unclaimed work item of the running render launch */
-    unsigned int _pad;
-    unsigned long long phase_cycles[6]; /* diagnostic builds only (MIRT_PHASE_TIMING) */
-    unsigned long long broad_misses;    /* diagnostic builds only (MIRT_VERIFY_BROAD): must be 0 */
-    /* diagnostic builds only (MIRT_PHASE_TIMING), in s_memrealtime ticks (100 MHz): */
-    unsigned long long inv_start_max;   /* ~(earliest wave start) */
-    unsigned long long end_max;         /* latest wave end */
-    unsigned long long life_sum;        /* sum over waves of (end - start) */
-    unsigned long long n_waves;
-    unsigned long long start_sum;       /* sum over waves of their start tick minus the launch's base tick (stats->queue time): see host */
-    unsigned long long idle_sum;        /* sum over waves of (end of the wave - its last iteration with a full complement of work): the drain */
-    unsigned long long bvh_lane_steps, bvh_wave_steps, bvh_leaf_rounds, bvh_lane_leaves; /* -DMIRT_PHASE_TIMING -DMIRT_BVH_COUNTERS */
-    unsigned long long diag[48]; /* -DMIRT_PHASE_TIMING: MIRT_DIAG, [k] wave-level entries of block k, [24 + k] lanes that entered it */
-};
 
 template <class R> __device__ inline R wave_sum_u(R v) {
 #pragma unroll

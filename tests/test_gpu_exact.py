@@ -119,7 +119,7 @@ def test_stress_scene_radiance_bit_exact(oracle, prec):
 
 @pytest.mark.parametrize("n", [505, 512, 513, 700, 1024])
 def test_f32_radiance_bit_exact_across_the_lds_layouts(oracle, n):
-    """The matrix-pipe kernel has two LDS layouts: up to 512 sorted slots with 640 material records, up to 1024 slots with
+    """The matrix-pipe kernel has two LDS layouts: up to 512 sorted slots with 512 material records, up to 1024 slots with
     184 (these scenes have ~0.9 n materials: LDS copy below 513, HBM/L2 above).  Either side of the boundary the frame is
     the oracle's f32-spec frame bit for bit, and the vector-ALU kernel's."""
     sc, cam = presets.stress_scene(n, 3), presets.stress_camera(96, 3, 12)

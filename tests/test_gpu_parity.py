@@ -688,7 +688,7 @@ def test_many_samples_few_pixels_vs_oracle(oracle, scenes):
 
 @pytest.mark.parametrize("n", [641, 800, 1100])
 def test_more_materials_than_the_lds_table_holds(oracle, n):
-    """One material per sphere: beyond 640 materials the matrix-pipe kernel reads material records from HBM/L2 instead of
+    """One material per sphere: beyond the LDS table (512 / 184 records by layout) the matrix-pipe kernel reads material records from HBM/L2 instead of
     its LDS copy (and beyond 1024 spheres everything streams); radiance against the oracle either way."""
     rng = np.random.default_rng(n)
     sc = Scene()
