@@ -1,6 +1,8 @@
-//! Raw FFI declarations for include/mirt.h (ABI version 1).  Layouts are `#[repr(C)]` copies of the C structs;
+//! Raw FFI declarations for include/mirt.h (ABI version 2).  Layouts are `#[repr(C)]` copies of the C structs;
 //! `tests/test_abi.py` pins the C side's sizes and offsets, and the constants below restate them so that a
-//! mismatch fails at compile time on the Rust side.
+//! mismatch fails at compile time on the Rust side.  This file has never seen a compiler (no cargo / rustc in
+//! the build image): `tests/test_ffi_drift.py` parses it next to the header and fails when the two disagree on
+//! an entry point, its arity, a constant, a struct's fields or a struct's size.
 #![allow(non_camel_case_types)]
 
 use std::os::raw::{c_char, c_int, c_void};
@@ -28,6 +30,8 @@ pub const MIRT_FLAG_COMPACT_ROWS: u32 = 1;
 pub const MIRT_FLAG_BVH: u32 = 2;
 pub const MIRT_FLAG_VALU_BROAD: u32 = 4;
 pub const MIRT_FLAG_DEFER_STATS: u32 = 8;
+pub const MIRT_FLAG_MX_SMALL: u32 = 16; // tuning / test switch, image-neutral
+pub const MIRT_STATIC_SCRATCH_BYTES: u64 = 128 << 20; // the device array behind mirt_render_device_static
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -134,7 +138,7 @@ pub const MIRT_GATHER_TO_ROOT: u32 = 0;
 pub const MIRT_GATHER_ALLGATHER: u32 = 1;
 
 #[repr(C)]
-#[derive(Clone, Copy, Debug)]
+#[derive(Clone, Copy, Debug, Default)]
 pub struct mirt_node_stats {
     pub segments: u64,
     pub nan_pixels: u64,
@@ -166,6 +170,7 @@ const _: () = assert!(std::mem::size_of::<mirt_sphere>() == 64);
 const _: () = assert!(std::mem::size_of::<mirt_camera>() == 192);
 const _: () = assert!(std::mem::size_of::<mirt_opts>() == 48);
 const _: () = assert!(std::mem::size_of::<mirt_stats>() == 72);
+const _: () = assert!(std::mem::size_of::<mirt_node_stats>() == 304);
 
 extern "C" {
     pub fn mirt_abi_version() -> c_int;
