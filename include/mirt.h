@@ -204,8 +204,9 @@ int mirt_render(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts
  * A scene handle owns ONE work queue, ONE set of counters and ONE workspace of partial sums: render calls
  * on the same handle are ordered one behind the other whatever their streams (each launch records an event,
  * the next one's stream waits for it), so a second call on another stream is safe but does not overlap the
- * first - keep one handle per frame in flight for that.  Host threads sharing a handle are serialised for
- * the duration of the enqueue; distinct handles are independent. */
+ * first - keep one handle per frame in flight for that.  Host threads sharing a handle are serialised: for
+ * the duration of the enqueue in the _device entry points, for the whole call in mirt_render / mirt_render_pass
+ * (whose staging frames belong to the handle) and in mirt_render_wait; distinct handles are independent. */
 int mirt_render_device(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
                        void* d_rgb_linear, uint8_t* d_rgb8, void* stream, mirt_stats* stats);
 int mirt_primary_hits_device(const mirt_scene* scene, const mirt_camera* cam, const mirt_opts* opts,
@@ -216,7 +217,8 @@ int mirt_primary_hits_device(const mirt_scene* scene, const mirt_camera* cam, co
  * counters / work-queue head, its per-item partial sums and (MIRT_F64) its per-lane attenuation stacks live in a
  * file-scope device array of MIRT_STATIC_SCRATCH_BYTES that each GPU the library runs on holds until the process ends,
  * and the call makes no hipMalloc / hipFree / event or host allocation of any kind (everything else it needs was made by
- * mirt_scene_create).  Limits: a call whose partial sums (3 reals per pixel of the part and chunk of samples, see
+ * mirt_scene_create: operands, events, the occupancy figures of every render kernel; tests/test_zz_no_alloc.py runs the
+ * call under stream capture and replays the graph).  Limits: a call whose partial sums (3 reals per pixel of the part and chunk of samples, see
  * mirt_pass_granularity; + 24 bytes x max_bounce_depth per lane of the grid in MIRT_F64) exceed the array is refused with
  * MIRT_ERR_TOO_LARGE - e.g. 400x225x100 spp in f32 fits, 1920x1080x64 spp does not; a camera so far outside the scene
  * that the matrix-pipe operands have to be rebuilt at another scale is refused with MIRT_ERR_INVALID until one

@@ -71,10 +71,12 @@ struct mirt_scene {
     /* A handle owns ONE work queue, ONE set of counters and ONE workspace.  Every render launch on the handle records
      * ev_busy behind its kernels and the next launch - on whatever stream - waits for it first, so two calls on one handle
      * never run side by side (callers that want frames in flight use one handle per frame in flight).  `lock` serialises
-     * host threads that share a handle for the duration of the enqueue. */
+     * host threads that share a handle: the _device entry points hold it for the duration of the enqueue, the host-buffer
+     * ones (mirt_render, mirt_render_pass: they grow, clear and copy back the handle's staging frames) and mirt_render_wait
+     * for the whole call.  Recursive, because the host-buffer calls go through the _device ones. */
     mutable hipEvent_t ev_busy = nullptr;
     mutable bool launched = false;
-    mutable std::mutex lock;
+    mutable std::recursive_mutex lock;
     /* device frames behind the host-buffer entry points (mirt_render / mirt_render_pass), grown on demand like `partial` */
     mutable void* stage[3] = {nullptr, nullptr, nullptr};
     mutable size_t stage_bytes[3] = {0, 0, 0};
@@ -650,10 +652,14 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
                 grid = std::min<uint64_t>(grid, fit);
                 att = (R*)(ws.fixed_base + used);
             } else {
-                const uint64_t att_need = per_block * grid;
-                if (att_need > MIRT_ATT_STACK_LIMIT)
+                /* as above: a smaller grid renders the same image, so a very deep bounce limit shrinks the grid to the blocks whose
+                 * stacks fit MIRT_ATT_STACK_LIMIT and only fails if not even one does (such depths rendered before the
+                 * stacks existed) */
+                if (per_block > MIRT_ATT_STACK_LIMIT)
                     return fail(MIRT_ERR_TOO_LARGE, "f64 parity mode keeps one attenuation per bounce and lane: max_bounce_depth " + std::to_string(cam->max_bounce_depth) +
-                                                        " needs " + std::to_string(att_need) + " bytes (limit 8 GiB)");
+                                                        " needs " + std::to_string(per_block) + " bytes for one block (limit 8 GiB)");
+                grid = std::min<uint64_t>(grid, MIRT_ATT_STACK_LIMIT / per_block);
+                const uint64_t att_need = per_block * grid;
                 if ((rc = ws_grow(ws.att, ws.att_bytes, (size_t)att_need, "the f64 attenuation stacks"))) return rc;
                 att = (R*)*ws.att;
             }
@@ -865,6 +871,10 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
         if (e != hipSuccess) { mirt_scene_destroy(s); return fail(MIRT_ERR_HIP, std::string("scene set-up: ") + hipGetErrorString(e)); }
         unsigned char* sp = nullptr;
         if ((rc = static_scratch_ptr(device, &sp))) { mirt_scene_destroy(s); return rc; }
+        /* resident blocks per CU of every render kernel this scene can select: asked here, so that no render call - least of
+         * all mirt_render_device_static - ever reaches hipOccupancyMaxActiveBlocksPerMultiprocessor or grows the cache */
+        for (int k = 0; k <= 6; ++k) (void)occupancy_of(render_fn(float(), k), k == 1 ? (int)MIRT_BLOCK : (int)MIRT_F32_BLOCK);
+        for (int k : {0, 3}) (void)occupancy_of(render_fn(double(), k), (int)MIRT_BLOCK);
         /* operands for a camera inside or near the scene (the scale then follows from the scene's extent alone) */
         mirt_camera c0;
         memset(&c0, 0, sizeof(c0));
@@ -898,7 +908,7 @@ int mirt_primary_hits_device(const mirt_scene* s, const mirt_camera* cam, const 
     if (!d_id) return fail(MIRT_ERR_INVALID, "id output is required");
     DevPart part;
     if ((rc = make_part(cam, o, &part))) return rc;
-    std::lock_guard<std::mutex> guard(s->lock);
+    std::lock_guard<std::recursive_mutex> guard(s->lock);
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     int mx_e = 0;
@@ -994,6 +1004,7 @@ static void fill_stats(const mirt_scene* s, uint32_t flags, const DevStats& h, f
 }
 int mirt_render_wait(const mirt_scene* s, mirt_stats* stats) {
     if (!s) return fail(MIRT_ERR_INVALID, "null argument");
+    std::lock_guard<std::recursive_mutex> guard(s->lock);
     if (!s->pending) return fail(MIRT_ERR_INVALID, "no deferred render outstanding on this scene handle");
     s->pending = false;
     hipError_t e = hipEventSynchronize(s->ev2);
@@ -1019,7 +1030,7 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
     if (rc) return rc;
     DevPart part;
     if ((rc = make_part(cam, o, &part))) return rc;
-    std::lock_guard<std::mutex> guard(s->lock);
+    std::lock_guard<std::recursive_mutex> guard(s->lock);
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1126,6 +1137,7 @@ int mirt_render(const mirt_scene* s, const mirt_camera* cam, const mirt_opts* o,
     if (rc) return rc;
     if (o->flags & MIRT_FLAG_COMPACT_ROWS) return fail(MIRT_ERR_INVALID, "host-buffer calls write full frames; use the _device entry point for compact bands");
     if (o->flags & MIRT_FLAG_DEFER_STATS) return fail(MIRT_ERR_INVALID, "host-buffer calls return when the work is done; MIRT_FLAG_DEFER_STATS is for mirt_render_device / mirt_render_pass_device");
+    std::lock_guard<std::recursive_mutex> guard(s->lock); /* the staging frames are the handle's: held until they are copied back */
     HIP_TRY(hipSetDevice(s->device));
     size_t n = (size_t)cam->img_width * cam->img_height * 3;
     size_t rsz = o->precision == MIRT_F64 ? 8 : 4;
@@ -1153,6 +1165,7 @@ int mirt_render_pass(const mirt_scene* s, const mirt_camera* cam, const mirt_opt
     if (o->flags & MIRT_FLAG_COMPACT_ROWS) return fail(MIRT_ERR_INVALID, "host-buffer calls write full frames; use the _device entry point for compact bands");
     if (o->flags & MIRT_FLAG_DEFER_STATS) return fail(MIRT_ERR_INVALID, "host-buffer calls return when the work is done; MIRT_FLAG_DEFER_STATS is for mirt_render_device / mirt_render_pass_device");
     if (!accum) return fail(MIRT_ERR_INVALID, "pass: the accumulation buffer is required");
+    std::lock_guard<std::recursive_mutex> guard(s->lock); /* as in mirt_render */
     HIP_TRY(hipSetDevice(s->device));
     const size_t n = (size_t)cam->img_width * cam->img_height * 3, rsz = o->precision == MIRT_F64 ? 8 : 4;
     void* d_acc = stage_frame(s, 2, n * rsz);

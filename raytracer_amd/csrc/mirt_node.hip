@@ -179,15 +179,16 @@ void mirt_node_destroy(mirt_node* n) {
 
 uint32_t mirt_node_device_count(const mirt_node* n) { return n ? (uint32_t)n->dev.size() : 0u; }
 
-/* d_rgb_linear / d_rgb8: device pointers on the ROOT device (device_ids[0]), full frames; either may be NULL. */
-int mirt_node_render_device(mirt_node* n, const mirt_camera* cam, const mirt_opts* opts, uint32_t gather, void* d_rgb_linear, uint8_t* d_rgb8,
-                            mirt_node_stats* stats) {
-    if (!n || !cam || !opts) return nfail(MIRT_ERR_INVALID, "null argument");
+} /* extern "C" */
+
+/* The body of mirt_node_render_device; the caller holds n->lock (mirt_node_render keeps it from growing its frames until it has
+ * copied them back, so that no second thread frees a frame in between). */
+static int node_render_locked(mirt_node* n, const mirt_camera* cam, const mirt_opts* opts, uint32_t gather, void* d_rgb_linear, uint8_t* d_rgb8,
+                              mirt_node_stats* stats) {
     if (gather != MIRT_GATHER_TO_ROOT && gather != MIRT_GATHER_ALLGATHER) return nfail(MIRT_ERR_INVALID, "unknown gather kind");
     if (opts->flags & (MIRT_FLAG_COMPACT_ROWS | MIRT_FLAG_DEFER_STATS)) return nfail(MIRT_ERR_INVALID, "the node sets MIRT_FLAG_COMPACT_ROWS / MIRT_FLAG_DEFER_STATS itself");
     if (opts->part_count > 1 || opts->part_index != 0) return nfail(MIRT_ERR_INVALID, "the node partitions the frame itself (part_index / part_count must be 0 / 0 or 1)");
     if (opts->precision != MIRT_F32 && opts->precision != MIRT_F64) return nfail(MIRT_ERR_INVALID, "mirt_opts.precision must be 32 or 64");
-    std::lock_guard<std::mutex> guard(n->lock);
     const auto wall0 = std::chrono::steady_clock::now();
     const uint32_t N = (uint32_t)n->dev.size(), W = cam->img_width, H = cam->img_height, S = opts->strip_rows ? opts->strip_rows : 8u;
     if (W == 0 || H == 0) return nfail(MIRT_ERR_INVALID, "empty image");
@@ -221,25 +222,38 @@ int mirt_node_render_device(mirt_node* n, const mirt_camera* cam, const mirt_opt
     o.strip_rows = S;
     o.part_count = N;
     o.flags |= MIRT_FLAG_COMPACT_ROWS | MIRT_FLAG_DEFER_STATS;
+    /* From the first launch on there is ONE way out on failure: every replica that took a launch (MIRT_FLAG_DEFER_STATS) has its
+     * statistics collected and its stream drained first - a handle left `pending` refuses every later render, so one transient
+     * HIP / RCCL error would otherwise make the node unusable for good. */
+    uint32_t launched = 0;
+    auto bail = [&](int code, const std::string& msg) {
+        for (uint32_t j = 0; j < launched; ++j) {
+            (void)mirt_render_wait(n->dev[j].scene, nullptr);
+            if (hipSetDevice(n->dev[j].id) == hipSuccess) (void)hipStreamSynchronize(n->dev[j].stream);
+        }
+        return nfail(code, msg);
+    };
+#define NODE_HIP_L(expr)                                                                                       \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return bail(MIRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
     for (uint32_t i = 0; i < N; ++i) {
         Dev& d = n->dev[i];
         o.part_index = i;
         int rc = mirt_render_device(d.scene, cam, &o, want[0] ? d.band[0] : nullptr, want[1] ? (uint8_t*)d.band[1] : nullptr, d.stream, nullptr);
-        if (rc) {
-            std::string msg = mirt_last_error();
-            for (uint32_t j = 0; j < i; ++j) (void)mirt_render_wait(n->dev[j].scene, nullptr);
-            return nfail(rc, "device " + std::to_string(d.id) + ": " + msg);
-        }
+        if (rc) return bail(rc, "device " + std::to_string(d.id) + ": " + std::string(mirt_last_error()));
+        launched = i + 1;
     }
     /* the one exchange step, on each device's own stream behind its band */
     Dev& root = n->dev[0];
-    NODE_HIP(hipSetDevice(root.id));
-    NODE_HIP(hipEventRecord(n->ev[0], root.stream));
+    NODE_HIP_L(hipSetDevice(root.id));
+    NODE_HIP_L(hipEventRecord(n->ev[0], root.stream));
     for (int k = 0; k < 2; ++k) {
         if (!want[k]) continue;
         const size_t count = (size_t)rows0 * W * px_bytes[k]; /* bytes: the bands travel as ncclUint8, whatever they hold */
-        NODE_NCCL(R->GroupStart());
-        ncclResult_t gr = ncclSuccess;
+        ncclResult_t gr = R->GroupStart();
+        if (gr != ncclSuccess) return bail(MIRT_ERR_HIP, std::string("ncclGroupStart: ") + R->GetErrorString(gr));
         for (uint32_t i = 0; i < N && gr == ncclSuccess; ++i) {
             Dev& d = n->dev[i];
             if (hipSetDevice(d.id) != hipSuccess) { gr = ncclUnhandledCudaError; break; }
@@ -252,25 +266,20 @@ int mirt_node_render_device(mirt_node* n, const mirt_camera* cam, const mirt_opt
                         gr = R->Recv((unsigned char*)root.all[k] + (size_t)r * count, count, ncclUint8, (int)r, root.comm, root.stream);
             }
         }
-        ncclResult_t ge = R->GroupEnd();
-        if (gr != ncclSuccess || ge != ncclSuccess) {
-            for (uint32_t j = 0; j < N; ++j) (void)mirt_render_wait(n->dev[j].scene, nullptr);
-            return nfail(MIRT_ERR_HIP, std::string("RCCL exchange: ") + R->GetErrorString(gr != ncclSuccess ? gr : ge));
-        }
+        ncclResult_t ge = R->GroupEnd(); /* always: a group left open would swallow the next call's collectives */
+        if (gr != ncclSuccess || ge != ncclSuccess) return bail(MIRT_ERR_HIP, std::string("RCCL exchange: ") + R->GetErrorString(gr != ncclSuccess ? gr : ge));
     }
-    NODE_HIP(hipSetDevice(root.id));
-    NODE_HIP(hipEventRecord(n->ev[1], root.stream));
+    NODE_HIP_L(hipSetDevice(root.id));
+    NODE_HIP_L(hipEventRecord(n->ev[1], root.stream));
     /* K4 on the root */
     int rc = MIRT_OK;
     if (want[0]) rc = mirt_deinterleave_device(root.all[0], (size_t)rows0 * W * px_bytes[0], N, S, W, H, (uint32_t)px_bytes[0], d_rgb_linear, root.stream);
     if (!rc && want[1]) rc = mirt_deinterleave_device(root.all[1], (size_t)rows0 * W * px_bytes[1], N, S, W, H, (uint32_t)px_bytes[1], d_rgb8, root.stream);
-    if (rc) {
-        std::string msg = mirt_last_error();
-        for (uint32_t j = 0; j < N; ++j) (void)mirt_render_wait(n->dev[j].scene, nullptr);
-        return nfail(rc, msg);
-    }
-    NODE_HIP(hipEventRecord(n->ev[2], root.stream));
-    /* wait: peers first (their sends), then the root; collect the per-device statistics */
+    if (rc) return bail(rc, std::string(mirt_last_error()));
+    NODE_HIP_L(hipEventRecord(n->ev[2], root.stream));
+#undef NODE_HIP_L
+    /* wait: peers first (their sends), then the root; collect the per-device statistics.  Every replica is collected whatever
+     * the others return (nothing stays pending); a replica that failed contributes zeros. */
     mirt_node_stats local;
     memset(&local, 0, sizeof(local));
     local.n_devices = N;
@@ -280,11 +289,13 @@ int mirt_node_render_device(mirt_node* n, const mirt_camera* cam, const mirt_opt
     for (uint32_t i = 0; i < N; ++i) {
         Dev& d = n->dev[i];
         mirt_stats st;
+        memset(&st, 0, sizeof(st));
         int rc2 = mirt_render_wait(d.scene, &st);
-        if (!rc2) {
+        if (rc2) memset(&st, 0, sizeof(st));
+        {
             hipError_t e = hipSetDevice(d.id);
             if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
-            if (e != hipSuccess) rc2 = nfail(MIRT_ERR_HIP, hipGetErrorString(e));
+            if (e != hipSuccess && !rc2) rc2 = nfail(MIRT_ERR_HIP, hipGetErrorString(e));
         }
         if (rc2 && !first_rc) { first_rc = rc2; first_msg = mirt_last_error(); }
         local.segments += st.segments;
@@ -304,6 +315,16 @@ int mirt_node_render_device(mirt_node* n, const mirt_camera* cam, const mirt_opt
     return MIRT_OK;
 }
 
+extern "C" {
+
+/* d_rgb_linear / d_rgb8: device pointers on the ROOT device (device_ids[0]), full frames; either may be NULL. */
+int mirt_node_render_device(mirt_node* n, const mirt_camera* cam, const mirt_opts* opts, uint32_t gather, void* d_rgb_linear, uint8_t* d_rgb8,
+                            mirt_node_stats* stats) {
+    if (!n || !cam || !opts) return nfail(MIRT_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(n->lock);
+    return node_render_locked(n, cam, opts, gather, d_rgb_linear, d_rgb8, stats);
+}
+
 /* host buffers: what a drop-in Camera::render calls */
 int mirt_node_render(mirt_node* n, const mirt_camera* cam, const mirt_opts* opts, uint32_t gather, void* rgb_linear, uint8_t* rgb8, mirt_node_stats* stats) {
     if (!n || !cam || !opts) return nfail(MIRT_ERR_INVALID, "null argument");
@@ -311,14 +332,14 @@ int mirt_node_render(mirt_node* n, const mirt_camera* cam, const mirt_opts* opts
     const size_t npx = (size_t)cam->img_width * cam->img_height, rsz = opts->precision == MIRT_F64 ? 8 : 4;
     const size_t bytes[2] = {npx * 3 * rsz, npx * 3};
     void* d[2] = {nullptr, nullptr};
-    {
-        std::lock_guard<std::mutex> guard(n->lock);
-        if (hipSetDevice(n->dev[0].id) != hipSuccess) return nfail(MIRT_ERR_HIP, "hipSetDevice failed");
-        if (rgb_linear) { int rc = grow(&n->frame[0], &n->frame_bytes[0], bytes[0]); if (rc) return rc; d[0] = n->frame[0]; }
-        if (rgb8) { int rc = grow(&n->frame[1], &n->frame_bytes[1], bytes[1]); if (rc) return rc; d[1] = n->frame[1]; }
-    }
+    /* the lock is held from growing the node's frames to copying them back: a second thread on the same node waits here
+     * instead of freeing or overwriting a frame this call still reads */
+    std::lock_guard<std::mutex> guard(n->lock);
+    if (hipSetDevice(n->dev[0].id) != hipSuccess) return nfail(MIRT_ERR_HIP, "hipSetDevice failed");
+    if (rgb_linear) { int rc = grow(&n->frame[0], &n->frame_bytes[0], bytes[0]); if (rc) return rc; d[0] = n->frame[0]; }
+    if (rgb8) { int rc = grow(&n->frame[1], &n->frame_bytes[1], bytes[1]); if (rc) return rc; d[1] = n->frame[1]; }
     mirt_node_stats local;
-    int rc = mirt_node_render_device(n, cam, opts, gather, d[0], (uint8_t*)d[1], &local);
+    int rc = node_render_locked(n, cam, opts, gather, d[0], (uint8_t*)d[1], &local);
     if (rc) return rc;
     if (hipSetDevice(n->dev[0].id) != hipSuccess) return nfail(MIRT_ERR_HIP, "hipSetDevice failed");
     if (rgb_linear && hipMemcpy(rgb_linear, d[0], bytes[0], hipMemcpyDeviceToHost) != hipSuccess) return nfail(MIRT_ERR_HIP, "copy back failed");

@@ -236,6 +236,44 @@ def test_two_calls_on_one_handle_on_two_streams_are_ordered():
     assert st.segments > 0
 
 
+def test_two_host_threads_share_one_handle():
+    """include/mirt.h: "host threads sharing a handle are serialised".  The host-buffer entry points grow, clear and copy
+    back staging frames the handle owns, so two threads on one handle must queue up for the WHOLE call (the lock
+    used to cover the enqueue only - a second thread could free or overwrite a frame the first was still copying from).
+    ctypes releases the GIL for the duration of a call, so the two threads really are inside the library together."""
+    import threading
+
+    sc = presets.bouncing_balls_scene(1)
+    sc.device_scene(0)
+    cams = [presets.bouncing_balls_camera(256, 4, 20), presets.bouncing_balls_camera(96, 2, 8)]  # different frame sizes: the staging frames regrow
+    refs = [c.render_arrays(sc, precision=abi.F32, seed=13) for c in cams]
+    bad = []
+
+    def worker(k):
+        cam = presets.bouncing_balls_camera(256, 4, 20) if k == 0 else presets.bouncing_balls_camera(96, 2, 8)
+        for _ in range(6):
+            lin, rgb8 = cam.render_arrays(sc, precision=abi.F32, seed=13)
+            if not (np.array_equal(bits(lin), bits(refs[k][0])) and np.array_equal(rgb8, refs[k][1])):
+                bad.append(k)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in (0, 1, 0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, bad
+
+
+def test_f64_deep_bounce_limit_shrinks_the_grid_instead_of_failing(oracle):
+    """the f64 attenuation stacks (24 B x max_bounce_depth per lane) used to refuse bounce limits whose stacks for
+    the FULL grid passed 8 GiB; any grid size renders the same image, so the grid now shrinks to what fits."""
+    sc, cam = balls_without_image(1), lensless_camera(64, 2, 400000)  # 2.4 GB of stacks per block: 3 blocks fit
+    lin, _ = cam.render_arrays(sc, precision=abi.F64, seed=3)
+    ref_cam = lensless_camera(64, 2, 400000)
+    o_lin, _, o_seg, _ = oracle.render(sc.flat, ref_cam.pod, abi.F64, seed=3, use_bvh=True, threads=8)
+    assert cam.last_stats["segments"] == o_seg and np.array_equal(bits(lin), bits(o_lin))
+
+
 def test_image_depends_on_arguments_only(monkeypatch):
     """No entry point reads the environment: the variables round 1's library obeyed change nothing any more, and the
     work-item size travels in mirt_opts."""

@@ -80,3 +80,40 @@ def test_static_entry_point_refuses_what_does_not_fit():
     st = abi.MirtStats()
     abi.check(lib.mirt_render_device_static(ds.handle, C.byref(c1.pod), C.byref(o1), out1.data_ptr(), None, None, C.byref(st)))
     assert st.segments > 400 * 225 * 100
+
+
+def test_static_entry_point_allocates_nothing_and_can_be_captured():
+    """the header promises "no hipMalloc / hipFree / event or host allocation of any kind" - checked, not only
+    claimed: (a) free device memory is the same before and after a first static call on a fresh handle (the occupancy cache
+    and the operands were filled by mirt_scene_create); (b) the call runs under stream capture in torch's global capture
+    mode, where an allocating HIP call is an error, and the replayed graph writes the frame of mirt_render_device."""
+    import torch
+
+    lib = abi.load()
+    sc = presets.bouncing_balls_scene(2)
+    ds = sc.device_scene(0)
+    cam = presets.bouncing_balls_camera(160, 4, 20)
+    o = cam.opts(precision=abi.F32, seed=8)
+    out = torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    abi.check(lib.mirt_render_device_static(ds.handle, C.byref(cam.pod), C.byref(o), out.data_ptr(), None, None, None))
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0, (free0, free1)
+    first = out.clone()
+    ref = torch.zeros_like(out)
+    abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(o), ref.data_ptr(), None, None, None))
+    torch.cuda.synchronize()
+    assert torch.equal(first, ref)
+    out.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        abi.check(lib.mirt_render_device_static(ds.handle, C.byref(cam.pod), C.byref(o), out.data_ptr(), None, torch.cuda.current_stream().cuda_stream, None))
+    torch.cuda.synchronize()
+    assert not torch.equal(out, ref)  # capture records, it does not run
+    for _ in range(2):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
