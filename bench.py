@@ -4,7 +4,8 @@
 One "step" = one full render of the workload (BASELINE.json configs[2], the configuration the metric is quoted on:
 the ~485-sphere bouncing-balls scene, 1920x1080, 64 spp, depth 50) with the scene already resident in HBM.
 N GPUs (one process per GPU, torchrun): the frame is sharded in interleaved 8-row strips, every rank renders its
-band into HBM, the bands are gathered with RCCL (torch.distributed backend "nccl") and scattered into frame order
+band into HBM, the bands are gathered TO RANK 0 with RCCL (torch.distributed backend "nccl": grouped send/recv, every peer
+over its own xGMI link; --gather allgather selects the ring all-gather instead) and scattered into frame order
 by kernel K4.  Strong scaling: the frame is fixed, value = ray segments of the whole frame / time.
 On several GPUs up to 3 frames (--in-flight) are in flight at a time, each on its own stream and scene handle: the
 gather of one frame, and the few long paths that end it, run beside the next frame's kernel.  On one GPU the default
@@ -36,8 +37,27 @@ SIMDS_PER_CU = 4
 # figure).  Per segment, the `5` of SURVEY 8d (a = D.D) is 3 more instructions.
 MX_CYCLES_PER_WAVE_TILE = 4 * 32 + 32 * 2
 MX_CYCLES_PER_WAVE_SEGMENT = 3 * 2
-PROFILE_TAGS = {("balls1080p", 1): "r02_mx", ("balls1080p", 0): "r02_valu", ("stress10000", 1): "r02_stress10k", ("stress10000", 0): "r02_stress10k_valu",
-                ("textured", 5): "r02_textured"}
+# The same slots priced with the overlap the hardware gives (bench/mfma_coexec.hip, profiles/r02_microbench.txt): ~4.5 VALU
+# instructions issue for free in the 32-cycle shadow of each MFMA, so of the 32 per tile only 32 - 4 x 4.5 = 14 cost their
+# 2 cycles.  The lower (harder) of the two bounds; both are printed.
+MX_CYCLES_PER_WAVE_TILE_SHADOW = 4 * 32 + (32 - 4 * 4.5) * 2
+PROFILE_TAGS = {("balls1080p", 1): "r03_mx", ("balls1080p", 0): "r03_valu", ("stress10000", 1): "r03_stress10k", ("stress10000", 0): "r03_stress10k_valu",
+                ("textured", 5): "r03_textured"}
+PROFILE_FALLBACK = {"r03_": "r02_"}  # a workload not re-profiled this round falls back to the last round's committed passes
+
+
+def data_note(workload):
+    """`data` of the result line, per workload (the scenes are seeded restatements of what the reference builds or of what
+    BASELINE.json's configs describe; nothing is downloaded)."""
+    if workload == "balls1080p":
+        return "synthetic (seeded restatement of the reference's bouncing_balls_scene, main.rs:151-229; reference textures pre-decoded)"
+    if workload == "mars":
+        return "synthetic (the reference's mars_texture_scene, main.rs:136-149; reference texture pre-decoded)"
+    if workload == "textured":
+        return "synthetic (BASELINE configs[3]: two image-textured spheres + checker ground, built from the reference's texture files, pre-decoded)"
+    if workload.startswith("stress"):
+        return "synthetic (BASELINE configs[4]: seeded uniform field of static spheres, 70/20/10 % Lambertian/metal/glass; no reference counterpart)"
+    return "synthetic"
 
 
 def profile_traffic(tag, kernel):
@@ -48,6 +68,9 @@ def profile_traffic(tag, kernel):
     these kernels the raw FETCH_SIZE is the byte count (factor 1.04, not 2); applied as 1."""
     path = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.txt")
     if not os.path.exists(path):
+        for new, old in PROFILE_FALLBACK.items():
+            if tag.startswith(new) and os.path.exists(os.path.join(ROOT, "profiles", f"{old}{tag[len(new):]}_hbm_traffic.txt")):
+                return profile_traffic(old + tag[len(new):], kernel)
         return None
     vals = {}
     for line in open(path):
@@ -65,6 +88,9 @@ def profile_valu_rate(tag):
     """VALU wave-instructions per SIMD-cycle from the committed SQ pass profiles/<tag>_sq_pmc.txt (tools/pmc_report.py line)."""
     path = os.path.join(ROOT, "profiles", f"{tag}_sq_pmc.txt")
     if not os.path.exists(path):
+        for new, old in PROFILE_FALLBACK.items():
+            if tag.startswith(new) and os.path.exists(os.path.join(ROOT, "profiles", f"{old}{tag[len(new):]}_sq_pmc.txt")):
+                return profile_valu_rate(old + tag[len(new):])
         return None
     import re
 
@@ -183,7 +209,7 @@ def run_node(args, lib, scene, cam, scene_name, result_fd):
     out = {
         "metric": "Mrays/s at 1080p (ray segment = one closest-hit query)", "value": round(seg / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": n,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic (seeded restatement of the reference's scenes)",
+        "vs_baseline": None, "dtype": "f32" if args.precision == 32 else "f64", "data": data_note(args.workload),
         "config": {"workload": f"{scene_name}: {scene.flat.n_spheres} spheres, {W}x{H}, {cam.pod.samples_per_pixel} spp, depth {cam.pod.max_bounce_depth}",
                    "parallelism": f"one process, {n} GPU(s): mirt_node_render_device (scene replicas, interleaved 8-row strips, RCCL {args.gather} inside libmirt.so, K4 on device 0)",
                    "frames_in_flight": 1, "seed": args.seed},
@@ -220,7 +246,9 @@ def main():
     ap.add_argument("--node", action="store_true",
                     help="single process: drive --gpus N devices through the library's own multi-GPU entry point (mirt_node_render_device: scene replicas, "
                          "RCCL exchange inside libmirt.so) instead of one torch.distributed rank per GPU; prints one line of the same shape")
-    ap.add_argument("--gather", default="to_root", choices=["to_root", "allgather"], help="--node: the exchange that is timed (the other one is measured beside it)")
+    ap.add_argument("--gather", default="to_root", choices=["to_root", "allgather"],
+                    help="the exchange of the bands: to_root = every rank sends its band to rank 0 (grouped send/recv, each peer over its own xGMI link), "
+                         "allgather = ring all-gather (N x the bytes).  --node: the one that is timed (the other is measured beside it)")
     ap.add_argument("--force-dist", action="store_true", help="run the gather path with a process group of one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' lets N ranks rehearse the N>1 path on ONE GPU")
     args = ap.parse_args()
@@ -296,7 +324,8 @@ def main():
         sl.stream = torch.cuda.Stream() if depth > 1 else torch.cuda.current_stream()
         sl.band = torch.zeros((rows0, W, 3), dtype=real, device="cuda")
         sl.band8 = torch.zeros((rows0, W, 3), dtype=torch.uint8, device="cuda")
-        sl.allb = torch.zeros((world * rows0, W, 3), dtype=real, device="cuda") if use_dist else None
+        # gather-to-root: only rank 0 holds the gathered bands
+        sl.allb = torch.zeros((world * rows0, W, 3), dtype=real, device="cuda") if use_dist and (rank == 0 or args.gather == "allgather") else None
         sl.frame = torch.zeros((H, W, 3), dtype=real, device="cuda") if rank == 0 else None
         sl.busy = False
         # gloo rehearsal (N ranks on one GPU): the gather goes through pinned host copies made on the frame's own stream - torch's
@@ -304,7 +333,7 @@ def main():
         # producing stream is busy, flushed or not; host tensors are fine)
         host_gather = use_dist and args.backend != "nccl"
         sl.hband = torch.empty((rows0, W, 3), dtype=real, pin_memory=True) if host_gather else None
-        sl.hall = torch.empty((world * rows0, W, 3), dtype=real, pin_memory=True) if host_gather else None
+        sl.hall = torch.empty((world * rows0, W, 3), dtype=real, pin_memory=True) if host_gather and (rank == 0 or args.gather == "allgather") else None
         sl.copied = torch.cuda.Event() if host_gather else None
         sl.gather_pending = False
         ring.append(sl)
@@ -323,12 +352,20 @@ def main():
             # rehearsal: the frame's band has reached pinned memory behind its kernels; gather on the host, send the frame back.
             # It happens when the slot is recycled (or at the fence), so the frames of the other slots stay in flight meanwhile.
             sl.copied.synchronize()
-            td.all_gather_into_tensor(sl.hall, sl.hband)
-            with torch.cuda.stream(sl.stream):
-                sl.allb.copy_(sl.hall, non_blocking=True)
+            exchange(sl.hall, sl.hband)
+            if sl.allb is not None:
+                with torch.cuda.stream(sl.stream):
+                    sl.allb.copy_(sl.hall, non_blocking=True)
             if rank == 0:
                 abi.check(lib.mirt_deinterleave_device(sl.allb.data_ptr(), sl.band.numel() * sl.band.element_size(), world, S, W, H, elem, sl.frame.data_ptr(), sl.stream.cuda_stream))
             sl.gather_pending = False
+
+    def exchange(all_bands, my_band):
+        """The one exchange step of a frame, on torch's current stream (device tensors: RCCL) or on the host (gloo rehearsal)."""
+        if args.gather == "allgather":
+            dist.gather_bands_into(all_bands, my_band)
+        else:
+            dist.gather_bands_to_root_into(all_bands, my_band, rank, world)
 
     def step(f):
         sl = ring[f % depth]
@@ -345,7 +382,7 @@ def main():
             g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.stream(sl.stream):
                 g0.record()
-                dist.gather_bands_into(sl.allb, sl.band)  # RCCL all-gather over xGMI: the one exchange step
+                exchange(sl.allb, sl.band)  # RCCL over xGMI: the one exchange step
                 g1.record()
             gather_events.append((g0, g1))
             if rank == 0:
@@ -380,7 +417,9 @@ def main():
 
     seg = sum(s.segments for s in stats)
     flops = sum(18 * s.static_tests + 27 * s.moving_tests + 5 * s.segments for s in stats)
-    kern_ms = sum(s.kernel_ms for s in stats)
+    launch_ms = sum(s.kernel_ms for s in stats)                  # render kernel K2 + resolve kernel K2b (events around both)
+    resolve_ms = sum(s.resolve_ms for s in stats)                 # K2b alone
+    kern_ms = launch_ms - resolve_ms                              # K2 alone: the kernel the roofline names
     iters = sum(s.wave_iterations for s in stats)
     narrow = sum(s.narrow_tests for s in stats)
     if td is not None:
@@ -417,7 +456,11 @@ def main():
             measured_peak.value = 0.0
         tag = PROFILE_TAGS.get((args.workload, kind)) if (W, cam.pod.samples_per_pixel, world) in ((1920, 64, 1), (3840, 16, 1), (3840, 256, 1)) else None
         traffic = profile_traffic(tag, kernel_name) if tag else None
-        roof = {"kernel": kernel_name, "kernel_ms_avg": round(ms_avg, 3), "flops_per_segment": round(flops / max(seg, 1), 1),
+        roof = {"kernel": kernel_name, "kernel_ms_avg": round(ms_avg, 3), "resolve_kernel_ms_avg": round(resolve_ms / n_launch, 3),
+                "launch_ms_avg": round(launch_ms / n_launch, 3),
+                "timing_note": "kernel_ms_avg = the render kernel K2 alone (HIP events before K2 and between K2 and K2b on the launch stream); launch_ms_avg = K2 + the resolve "
+                               "kernel K2b, which is what a frame costs and what `value` is made of",
+                "flops_per_segment": round(flops / max(seg, 1), 1),
                 "algorithmic_tflops": round(achieved, 3),
                 "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": (traffic["file"] + " (FETCH_SIZE raw + WRITE_SIZE of the last launch; calibration in bench.py::profile_traffic)") if traffic else None,
@@ -436,9 +479,15 @@ def main():
             cyc = tiles * MX_CYCLES_PER_WAVE_TILE + MX_CYCLES_PER_WAVE_SEGMENT
             t_bound = (seg / 64.0) * cyc / (cus * SIMDS_PER_CU * NOMINAL_CLOCK_GHZ * 1e9)  # s for all timed launches of this rank
             peak = flops / t_bound / 1e12
+            cyc_sh = tiles * MX_CYCLES_PER_WAVE_TILE_SHADOW + MX_CYCLES_PER_WAVE_SEGMENT
+            t_bound_sh = (seg / 64.0) * cyc_sh / (cus * SIMDS_PER_CU * NOMINAL_CLOCK_GHZ * 1e9)
             roof.update({"bound": "valu+mfma issue", "achieved": round(achieved, 3), "peak": round(peak, 3), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "issue_cycles_per_wave_and_segment": cyc, "sphere_tiles": tiles, "clock_ghz": NOMINAL_CLOCK_GHZ, "simds": cus * SIMDS_PER_CU,
                          "bound_ms_per_launch": round(t_bound / n_launch * 1e3, 3),
+                         "bound_shadow_aware": {"issue_cycles_per_wave_and_segment": cyc_sh, "bound_ms_per_launch": round(t_bound_sh / n_launch * 1e3, 3),
+                                                "frac": round(t_bound_sh / t_priced, 4),
+                                                "note": "the same mandatory slots with the ~4.5 VALU instructions per MFMA that issue for free in its shadow taken off "
+                                                        "(bench/mfma_coexec.hip): the harder bound; `frac` above prices MFMA and VALU additively"},
                          "vs_fp32_valu_peak": round(achieved / FP32_VALU_PEAK_TFLOPS, 4)})
             note += (f"; bound = mandatory issue slots of the matrix-pipe broad phase: per wave and segment {tiles} tiles x (4 MFMA x 32 + 32 VALU x 2 cycles) + 6 = {cyc} SIMD-cycles, "
                      f"segments / 64 waves, {cus * SIMDS_PER_CU} SIMDs at the nominal {NOMINAL_CLOCK_GHZ} GHz; `peak` is that bound expressed in the same algorithmic flops, so frac = bound time / kernel time; "
@@ -470,10 +519,13 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32" if args.precision == 32 else "f64",
-            "data": "synthetic (seeded restatement of the reference's bouncing_balls_scene; reference textures pre-decoded)",
+            "data": data_note(args.workload),
             "config": {
                 "workload": f"{scene_name}: {scene.flat.n_spheres} spheres, {W}x{H}, {cam.pod.samples_per_pixel} spp, depth {cam.pod.max_bounce_depth}",
-                "parallelism": f"interleaved {S}-row strips over {world} GPU(s), RCCL all-gather of f32 RGB bands",
+                "parallelism": ("one GPU: the whole frame in one launch, no exchange" if world == 1 and not use_dist else
+                                f"interleaved {S}-row strips over {world} GPU(s), one process per GPU; bands ({'f32' if args.precision == 32 else 'f64'} RGB) "
+                                + ("gathered to rank 0 (grouped send/recv: each peer over its own xGMI link)" if args.gather == "to_root" else "ring all-gather")
+                                + f" with torch.distributed/{args.backend}, K4 on rank 0"),
                 "frames_in_flight": depth,
                 "seed": args.seed,
                 "closest_hit": ["brute-force LDS tile loop, broad phase on the vector ALU",
@@ -484,8 +536,14 @@ def main():
             },
             "roofline": roof,
             "multi_gpu": None if per_rank is None else {
-                "rccl_ranks": world, "backend": args.backend, "exchange": "all_gather_into_tensor of the f32 RGB bands, then K4 (mirt_deinterleave_device) on rank 0",
-                "band_bytes_per_rank": int(rows0 * W * elem),
+                "rccl_ranks": world, "backend": args.backend,
+                "exchange": ("torch.distributed.gather of the RGB bands to rank 0 (grouped send/recv)" if args.gather == "to_root" else "all_gather_into_tensor of the RGB bands")
+                            + ", then K4 (mirt_deinterleave_device) on rank 0",
+                "gather": args.gather, "band_bytes_per_rank": int(rows0 * W * elem),
+                "gather_bytes_per_rank": {"sent": int(rows0 * W * elem) if (args.gather == "to_root" and world > 1) or args.gather == "allgather" else 0,
+                                          "received_rank0": int(world * rows0 * W * elem),
+                                          "received_other_ranks": int(world * rows0 * W * elem) if args.gather == "allgather" else 0,
+                                          "note": "to_root: each peer's band crosses ONE xGMI link once; allgather (ring): every rank receives all bands"},
                 "band_kernel_ms_per_rank": [round(r_[0], 3) for r_ in per_rank],
                 "gather_ms_per_rank": [round(r_[1], 3) for r_ in per_rank],
                 "segments_per_rank": [int(r_[2]) for r_ in per_rank],
@@ -529,11 +587,14 @@ def main():
             ms3 = []
             for _ in range(3):
                 abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(o3), band.data_ptr(), band8.data_ptr(), stream, C.byref(st3)))
-                ms3.append(st3.kernel_ms)
+                ms3.append(st3.kernel_ms - st3.resolve_ms)  # K2 alone
             fl3 = 18 * st3.static_tests + 27 * st3.moving_tests + 5 * st3.segments
-            tf3 = fl3 / (min(ms3) * 1e-3) / 1e12
-            out["valu_broad"] = {"value": round(st3.segments / (min(ms3) * 1e-3) / 1e6, 3), "unit": "Mrays/s", "kernel": "render_kernel_f32", "kernel_ms": round(min(ms3), 3),
+            mean3 = sum(ms3) / len(ms3)
+            tf3 = fl3 / (mean3 * 1e-3) / 1e12  # the mean, as for the headline; the best launch beside it
+            out["valu_broad"] = {"value": round(st3.segments / (mean3 * 1e-3) / 1e6, 3), "unit": "Mrays/s", "kernel": "render_kernel_f32", "kernel_ms": round(mean3, 3),
+                                 "kernel_ms_min": round(min(ms3), 3), "launches": len(ms3),
                                  "bound": "valu_fp32", "achieved": round(tf3, 3), "peak": FP32_VALU_PEAK_TFLOPS, "frac": round(tf3 / FP32_VALU_PEAK_TFLOPS, 4),
+                                 "frac_best_launch": round(fl3 / (min(ms3) * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4),
                                  "frac_of_measured_peak": round(tf3 / measured_peak.value, 4) if measured_peak.value else None,
                                  "note": "same frame, same image, every (ray, sphere) pair on the vector ALU: the metric's % of FP32 VALU peak, in the algorithmic flops of SURVEY.md 8d "
                                          "(against the nominal 157.3 TFLOP/s and against this box's measured FMA peak)"}
@@ -561,6 +622,23 @@ def main():
                                       "kernel": "render_kernel_f64_mx" if k4 == 4 else "render_kernel_f64<2>",
                                       "note": "same scene and camera in binary64; its own RNG dimension layout, so a different (equally valid) image"}
             del band64
+        if world == 1 and not args.no_extras:
+            # report the f32-vs-f64 hit-id mismatch count of the deterministic map (camera.rs:247-254) at this size.
+            # Each precision is bit-exact against its own oracle instantiation (tests/test_gpu_parity.py); the two differ at
+            # silhouette pixels, where binary32 and binary64 disagree on which side of a sphere's edge a pixel corner lies.
+            cam0 = build_workload(args.workload, args.width, 0, args.depth)[1]
+            ids = {}
+            for prec in (32, 64):
+                d_id = torch.zeros((cam0.height, cam0.width), dtype=torch.int32, device="cuda")
+                o0 = cam0.opts(precision=prec, seed=args.seed)
+                abi.check(lib.mirt_primary_hits_device(ds.handle, C.byref(cam0.pod), C.byref(o0), d_id.data_ptr(), None, stream))
+                torch.cuda.synchronize()
+                ids[prec] = d_id
+            mism = int((ids[32] != ids[64]).sum().item())
+            out["parity"] = {"f32_vs_f64_hit_id_mismatches": mism, "pixels": cam0.width * cam0.height, "share": round(mism / (cam0.width * cam0.height), 7),
+                             "note": "deterministic primary-ray hit-id maps (no-AA branch) of this workload's scene at the bench resolution, MIRT_F32 against MIRT_F64 on the GPU; "
+                                     "each map is bit-exact against the oracle's instantiation of its own precision (tests/test_gpu_parity.py, tests/golden/); the f32 RADIANCE is "
+                                     "held per pixel to the reference's f64 arithmetic under the same uniforms in tests/test_gpu_f32_vs_reference.py (bars in DESIGN.md 2)"}
         if world == 1 and not args.no_cpu_baseline:
             base, mt = cpu_baseline(scene, cam, args.seed, args.cpu_seconds)
             out["cpu_baseline"] = base

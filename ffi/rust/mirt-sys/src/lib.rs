@@ -1,4 +1,4 @@
-//! Raw FFI declarations for include/mirt.h (ABI version 2).  Layouts are `#[repr(C)]` copies of the C structs;
+//! Raw FFI declarations for include/mirt.h (ABI version 3).  Layouts are `#[repr(C)]` copies of the C structs;
 //! `tests/test_abi.py` pins the C side's sizes and offsets, and the constants below restate them so that a
 //! mismatch fails at compile time on the Rust side.  This file has never seen a compiler (no cargo / rustc in
 //! the build image): `tests/test_ffi_drift.py` parses it next to the header and fails when the two disagree on
@@ -7,7 +7,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const MIRT_ABI_VERSION: u32 = 2;
+pub const MIRT_ABI_VERSION: u32 = 3;
 pub const MIRT_MISS_ID: u32 = 0xFFFF_FFFF;
 
 pub const MIRT_OK: c_int = 0;
@@ -130,6 +130,7 @@ pub struct mirt_stats {
     pub nan_pixels: u64,
     pub kernel_ms: f64,
     pub tree_segments: u64,
+    pub resolve_ms: f64, // of kernel_ms (K2 + K2b): the resolve kernel alone
 }
 
 pub const MIRT_NODE_MAX_DEVICES: usize = 16;
@@ -169,7 +170,7 @@ const _: () = assert!(std::mem::size_of::<mirt_material>() == 64);
 const _: () = assert!(std::mem::size_of::<mirt_sphere>() == 64);
 const _: () = assert!(std::mem::size_of::<mirt_camera>() == 192);
 const _: () = assert!(std::mem::size_of::<mirt_opts>() == 48);
-const _: () = assert!(std::mem::size_of::<mirt_stats>() == 72);
+const _: () = assert!(std::mem::size_of::<mirt_stats>() == 80);
 const _: () = assert!(std::mem::size_of::<mirt_node_stats>() == 304);
 
 extern "C" {

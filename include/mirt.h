@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MIRT_ABI_VERSION 2u
+#define MIRT_ABI_VERSION 3u /* 3: mirt_stats.resolve_ms */
 #define MIRT_MISS_ID 0xFFFFFFFFu /* hit-id of a ray that hits nothing (SURVEY.md §8c "Hit id definition") */
 
 typedef enum mirt_status {
@@ -167,9 +167,11 @@ typedef struct mirt_stats {
     uint64_t narrow_tests;    /* candidates (d >= 0) that reached the root computation            */
     uint64_t wave_iterations; /* wave-level passes of the segment loop (64 lanes each)            */
     uint64_t nan_pixels;      /* pixels whose radiance was NaN (reference would panic)            */
-    double kernel_ms;         /* hipEvent time of the dominant kernel, on the stream it ran on    */
+    double kernel_ms;         /* hipEvent time of the launch on the stream it ran on: the render kernel K2 */
+                              /* AND the resolve kernel K2b behind it                                      */
     uint64_t tree_segments;   /* of `segments`: traced through the bounding-volume tree (MIRT_FLAG_BVH);  */
                               /* those are not counted in *_tests                                          */
+    double resolve_ms;        /* of kernel_ms: the resolve kernel K2b alone (K2 = kernel_ms - resolve_ms) */
 } mirt_stats;
 
 typedef struct mirt_scene mirt_scene; /* opaque: device-resident flattened scene */

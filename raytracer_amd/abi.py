@@ -100,8 +100,9 @@ class MirtStats(C.Structure):
         ("narrow_tests", C.c_uint64),
         ("wave_iterations", C.c_uint64),
         ("nan_pixels", C.c_uint64),
-        ("kernel_ms", C.c_double),
+        ("kernel_ms", C.c_double),  # K2 + K2b
         ("tree_segments", C.c_uint64),
+        ("resolve_ms", C.c_double),  # of kernel_ms: K2b alone
     ]
 
     def asdict(self):

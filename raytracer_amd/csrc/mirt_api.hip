@@ -81,6 +81,7 @@ struct mirt_scene {
     mutable void* stage[3] = {nullptr, nullptr, nullptr};
     mutable size_t stage_bytes[3] = {0, 0, 0};
     mutable hipEvent_t ev0 = nullptr, ev1 = nullptr; /* timing events of render calls that ask for statistics (created with the scene) */
+    mutable hipEvent_t ev_mid = nullptr;             /* between the render kernel and the resolve kernel (mirt_stats.resolve_ms) */
     /* MIRT_FLAG_DEFER_STATS: the counters land in pinned host memory behind the launch, mirt_render_wait reads them */
     mutable hipEvent_t ev2 = nullptr;
     mutable DevStats* host_stats = nullptr;
@@ -565,7 +566,7 @@ static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStre
 template <class R>
 static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mirt_camera* cam, const mirt_opts* o, const DevPart& part, const Workspace& ws,
                          void* d_lin, uint8_t* d_rgb8, hipStream_t st, bool use_bvh, bool mx, uint32_t first_sample = 0, uint32_t sample_count = 0xFFFFFFFFu,
-                         void* d_accum = nullptr) {
+                         void* d_accum = nullptr, hipEvent_t ev_mid = nullptr) {
     /* closest-hit front end: 0 = brute force, VALU broad phase; 1 = tree in HBM/L2; 2 = tree, records and spheres resident in
      * LDS; 3 = brute force, broad phase on the matrix pipe; 4 = f32, a handful of spheres (render_kernel_f32_tiny);
      * 5 = 3 with the LDS layout for scenes of up to MIRT_MX_SMALL_RECORDS sorted slots (f32); 6 = 3 for scenes beyond the LDS,
@@ -674,6 +675,7 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
         launch_render_kernel((uint32_t)grid, block, bvh, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, rp, partial, ws.stats, att);
         HIP_TRY(hipGetLastError());
     }
+    if (ev_mid) HIP_TRY(hipEventRecord(ev_mid, st)); /* timed calls: where the render kernel ends and the resolve kernel begins */
     /* one wave per 64 pixels of a band row */
     const uint64_t rwaves = (uint64_t)part.local_rows * ((cam->img_width + 63u) / 64u);
     uint32_t rgrid = (uint32_t)((rwaves + MIRT_RESOLVE_WAVES - 1) / MIRT_RESOLVE_WAVES);
@@ -866,6 +868,7 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
         hipError_t e = hipEventCreate(&s->ev0);
         if (e == hipSuccess) e = hipEventCreate(&s->ev1);
         if (e == hipSuccess) e = hipEventCreate(&s->ev2);
+        if (e == hipSuccess) e = hipEventCreate(&s->ev_mid);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_busy, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void**)&s->host_stats, sizeof(DevStats), hipHostMallocDefault);
         if (e != hipSuccess) { mirt_scene_destroy(s); return fail(MIRT_ERR_HIP, std::string("scene set-up: ") + hipGetErrorString(e)); }
@@ -898,6 +901,7 @@ void mirt_scene_destroy(mirt_scene* s) {
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->ev2) (void)hipEventDestroy(s->ev2);
+    if (s->ev_mid) (void)hipEventDestroy(s->ev_mid);
     if (s->host_stats) (void)hipHostFree(s->host_stats);
     delete s;
 }
@@ -989,7 +993,7 @@ static void print_diagnostics(const DevStats& h) {
     }
 #endif
 }
-static void fill_stats(const mirt_scene* s, uint32_t flags, const DevStats& h, float ms, mirt_stats* stats) {
+static void fill_stats(const mirt_scene* s, uint32_t flags, const DevStats& h, float ms, mirt_stats* stats, float resolve_ms = 0.f) {
     memset(stats, 0, sizeof(*stats));
     stats->segments = h.segments;
     stats->tree_segments = (flags & MIRT_FLAG_BVH) ? h.segments : 0;
@@ -1001,6 +1005,7 @@ static void fill_stats(const mirt_scene* s, uint32_t flags, const DevStats& h, f
     stats->wave_iterations = h.wave_iters;
     stats->nan_pixels = h.nan_pixels;
     stats->kernel_ms = ms;
+    stats->resolve_ms = (resolve_ms > 0.f && resolve_ms <= ms) ? resolve_ms : 0.0; /* a call that launched nothing leaves the mid event where an earlier call put it */
 }
 int mirt_render_wait(const mirt_scene* s, mirt_stats* stats) {
     if (!s) return fail(MIRT_ERR_INVALID, "null argument");
@@ -1010,8 +1015,10 @@ int mirt_render_wait(const mirt_scene* s, mirt_stats* stats) {
     hipError_t e = hipEventSynchronize(s->ev2);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, s->ev0, s->ev1);
+    float rms = 0.f;
+    if (e == hipSuccess && hipEventElapsedTime(&rms, s->ev_mid, s->ev1) != hipSuccess) rms = 0.f; /* max_bounce_depth 0: no mid event was recorded */
     if (e != hipSuccess) return fail(MIRT_ERR_HIP, std::string("render: ") + hipGetErrorString(e));
-    if (stats) fill_stats(s, s->pending_flags, *s->host_stats, ms, stats);
+    if (stats) fill_stats(s, s->pending_flags, *s->host_stats, ms, stats, rms);
     print_diagnostics(*s->host_stats);
     return MIRT_OK;
 }
@@ -1061,8 +1068,9 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
         HIP_TRY(hipEventRecord(e0, st));
     }
     rc = o->precision == MIRT_F64
-             ? launch_render<double>(s, s->f64, cam, o, part, ws, d_lin, d_rgb8, st, false, mx, first_sample, sample_count, d_accum)
-             : launch_render<float>(s, s->f32, cam, o, part, ws, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0, mx, first_sample, sample_count, d_accum);
+             ? launch_render<double>(s, s->f64, cam, o, part, ws, d_lin, d_rgb8, st, false, mx, first_sample, sample_count, d_accum, e0 ? s->ev_mid : nullptr)
+             : launch_render<float>(s, s->f32, cam, o, part, ws, d_lin, d_rgb8, st, (o->flags & MIRT_FLAG_BVH) != 0, mx, first_sample, sample_count, d_accum,
+                                    e0 ? s->ev_mid : nullptr);
     if (!use_static) {
         /* also after a failed enqueue: whatever did get onto the stream still uses the handle's memory */
         if (hipEventRecord(s->ev_busy, st) == hipSuccess) s->launched = true;
@@ -1082,9 +1090,11 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
             memset(&h, 0, sizeof(h));
             float ms = 0.f;
             if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            float rms = 0.f;
+            if (e == hipSuccess && hipEventElapsedTime(&rms, s->ev_mid, e1) != hipSuccess) rms = 0.f;
             if (e == hipSuccess) e = hipMemcpy(&h, ws.stats, sizeof(h), hipMemcpyDeviceToHost);
             if (e != hipSuccess) rc = fail(MIRT_ERR_HIP, std::string("render: ") + hipGetErrorString(e));
-            fill_stats(s, o->flags, h, ms, stats);
+            fill_stats(s, o->flags, h, ms, stats, rms);
             print_diagnostics(h);
         }
     }

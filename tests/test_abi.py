@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = abi.load()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert lib.mirt_abi_version() == 2
+    assert lib.mirt_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header():
@@ -36,7 +36,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(abi.MirtSceneDesc) == 16 + 32
     assert C.sizeof(abi.MirtCamera) == 7 * 24 + 8 + 16
     assert C.sizeof(abi.MirtOpts) == 48
-    assert C.sizeof(abi.MirtStats) == 72
+    assert C.sizeof(abi.MirtStats) == 80
 
 
 def test_host_only_helpers():

@@ -50,6 +50,16 @@ def _worker(rank, world, port, height, width, strip, q):
             assert np.array_equal(got, full + np.float32(f))
         with pytest.raises(ValueError):
             dist.gather_bands_into(torch.zeros((world * max_rows + 1, width, 3)), torch.from_numpy(band))
+        # gather-to-root (what bench.py --gpus N does by default): only rank 0 holds a buffer, and it gets every band in its slot
+        root_buf = torch.full((world * max_rows, width, 3), -1.0) if rank == 0 else None
+        for f in range(3):
+            dist.gather_bands_to_root_into(root_buf, torch.from_numpy(band + np.float32(10 * f)), rank, world)
+            if rank == 0:
+                got = dist.deinterleave_host(root_buf.numpy().reshape(world, max_rows, width, 3), height, strip)
+                assert np.array_equal(got, full + np.float32(10 * f))
+        if rank == 0:
+            with pytest.raises(ValueError):
+                dist.gather_bands_to_root_into(torch.zeros((world * max_rows + 2, width, 3)), torch.from_numpy(band), rank, world)
         # the timing reduction bench.py does: max over ranks
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
