@@ -15,6 +15,8 @@ parts = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 lib = abi.load()
 scene, cam, name = bench.build_workload("balls1080p", 1920, 64, 50)
+cam.chunk_samples = int(os.environ.get("PROBE_CHUNK", "0"))  # mirt_opts.chunk_samples (0 = the library's choice)
+extra_flags = int(os.environ.get("PROBE_FLAGS", "0"))
 S = dist.DEFAULT_STRIP_ROWS
 handles = [DeviceScene(scene.flat, 0) for _ in range(4)]
 streams = [torch.cuda.Stream() for _ in range(4)]
@@ -22,7 +24,7 @@ for rank in sorted({0, parts // 2, parts - 1}):
     rows = dist.part_rows(cam.height, S, rank, parts)
     bands = [torch.zeros((rows, cam.width, 3), dtype=torch.float32, device="cuda") for _ in range(4)]
     bands8 = [torch.zeros((rows, cam.width, 3), dtype=torch.uint8, device="cuda") for _ in range(4)]
-    opts = cam.opts(precision=32, seed=1, strip_rows=S, part_index=rank, part_count=parts, flags=abi.FLAG_COMPACT_ROWS)
+    opts = cam.opts(precision=32, seed=1, strip_rows=S, part_index=rank, part_count=parts, flags=abi.FLAG_COMPACT_ROWS | extra_flags)
 
     def run(nh):
         for w in range(2):
