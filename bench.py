@@ -420,6 +420,7 @@ def main():
     launch_ms = sum(s.kernel_ms for s in stats)                  # render kernel K2 + resolve kernel K2b (events around both)
     resolve_ms = sum(s.resolve_ms for s in stats)                 # K2b alone
     kern_ms = launch_ms - resolve_ms                              # K2 alone: the kernel the roofline names
+    mx_tiles = sum(s.mx_tiles for s in stats)                     # (wave, tile) evaluations of the matrix-pipe kernels: what the tile cull left
     iters = sum(s.wave_iterations for s in stats)
     narrow = sum(s.narrow_tests for s in stats)
     if td is not None:
@@ -474,22 +475,28 @@ def main():
             # the kernel whose broad phase runs on the matrix pipe is bounded by the issue slots of the SIMD's shared VALU/MFMA port
             n_static = int(round(sum(s_.static_tests for s_ in stats) / max(seg, 1)))
             n_moving = int(round(sum(s_.moving_tests for s_ in stats) / max(seg, 1)))
-            slots = ((n_static + 3) // 4 * 4 + n_moving + 31) // 32 * 32  # the library's layout: statics padded to 4, the whole array to 32-sphere tiles
-            tiles = slots // 32
+            slots = (n_static + n_moving + 31) // 32 * 32  # the library's layout: the sorted array padded to whole 32-sphere tiles
+            tiles_all = slots // 32
+            # the tile cull: a wave evaluates the top tile and then only the tiles some ray of it can touch.  The bound prices the
+            # tiles that WERE evaluated (mirt_stats.mx_tiles, counted by the kernel), not the all-pairs count.
+            tiles = mx_tiles / max(iters, 1) if mx_tiles else float(tiles_all)
             cyc = tiles * MX_CYCLES_PER_WAVE_TILE + MX_CYCLES_PER_WAVE_SEGMENT
             t_bound = (seg / 64.0) * cyc / (cus * SIMDS_PER_CU * NOMINAL_CLOCK_GHZ * 1e9)  # s for all timed launches of this rank
             peak = flops / t_bound / 1e12
             cyc_sh = tiles * MX_CYCLES_PER_WAVE_TILE_SHADOW + MX_CYCLES_PER_WAVE_SEGMENT
             t_bound_sh = (seg / 64.0) * cyc_sh / (cus * SIMDS_PER_CU * NOMINAL_CLOCK_GHZ * 1e9)
             roof.update({"bound": "valu+mfma issue", "achieved": round(achieved, 3), "peak": round(peak, 3), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "issue_cycles_per_wave_and_segment": cyc, "sphere_tiles": tiles, "clock_ghz": NOMINAL_CLOCK_GHZ, "simds": cus * SIMDS_PER_CU,
+                         "issue_cycles_per_wave_and_segment": round(cyc, 1), "sphere_tiles": tiles_all, "tiles_evaluated_per_wave_iteration": round(tiles, 3),
+                         "pairs_evaluated_share": round(tiles / tiles_all, 4) if tiles_all else None,
+                         "clock_ghz": NOMINAL_CLOCK_GHZ, "simds": cus * SIMDS_PER_CU,
                          "bound_ms_per_launch": round(t_bound / n_launch * 1e3, 3),
                          "bound_shadow_aware": {"issue_cycles_per_wave_and_segment": cyc_sh, "bound_ms_per_launch": round(t_bound_sh / n_launch * 1e3, 3),
-                                                "frac": round(t_bound_sh / t_priced, 4),
+                                                "frac": round(t_bound_sh / t_priced, 4) if t_priced > 0 else None,
                                                 "note": "the same mandatory slots with the ~4.5 VALU instructions per MFMA that issue for free in its shadow taken off "
                                                         "(bench/mfma_coexec.hip): the harder bound; `frac` above prices MFMA and VALU additively"},
                          "vs_fp32_valu_peak": round(achieved / FP32_VALU_PEAK_TFLOPS, 4)})
-            note += (f"; bound = mandatory issue slots of the matrix-pipe broad phase: per wave and segment {tiles} tiles x (4 MFMA x 32 + 32 VALU x 2 cycles) + 6 = {cyc} SIMD-cycles, "
+            note += (f"; bound = mandatory issue slots of the matrix-pipe broad phase: per wave and segment {tiles:.2f} tiles evaluated (of {tiles_all}: the tile cull skips the tiles no ray of a wave "
+                     f"can touch; the count includes the top tile it tests first) x (4 MFMA x 32 + 32 VALU x 2 cycles) + 6 = {cyc:.0f} SIMD-cycles, "
                      f"segments / 64 waves, {cus * SIMDS_PER_CU} SIMDs at the nominal {NOMINAL_CLOCK_GHZ} GHz; `peak` is that bound expressed in the same algorithmic flops, so frac = bound time / kernel time; "
                      "`vs_fp32_valu_peak` is the algorithmic rate against the vector-ALU peak alone, which this kernel can exceed because 8 of the 9 VALU operations per pair moved to the "
                      "matrix pipe - the metric's '% of FP32 VALU peak' is `valu_broad.frac` (render_kernel_f32, every pair on the vector ALU)")
@@ -580,6 +587,25 @@ def main():
                                          "note": "same frame, three scene handles on three streams; the N > 1 runs keep frames in flight like this"}
             for e in extra:
                 e.close()
+        if world == 1 and kind in (1, 4) and mx_tiles and not args.no_extras:
+            # the same frame with EVERY (ray, sphere) pair on the matrix pipe (MIRT_FLAG_ALL_PAIRS: no tile cull): round 2's kernel, the all-pairs rate
+            oa = cam.opts(precision=args.precision, seed=args.seed, strip_rows=S, part_index=0, part_count=1, flags=abi.FLAG_COMPACT_ROWS | abi.FLAG_ALL_PAIRS)
+            sta = abi.MirtStats()
+            msa = []
+            banda = torch.zeros_like(band)
+            for _ in range(3):
+                abi.check(lib.mirt_render_device(ds.handle, C.byref(cam.pod), C.byref(oa), banda.data_ptr(), band8.data_ptr(), stream, C.byref(sta)))
+                msa.append(sta.kernel_ms - sta.resolve_ms)
+            if not torch.equal(banda, band):
+                raise SystemExit("the all-pairs frame differs from the culled frame")
+            mean_a = sum(msa) / len(msa)
+            cyc_a = tiles_all * MX_CYCLES_PER_WAVE_TILE + MX_CYCLES_PER_WAVE_SEGMENT
+            tb_a = (sta.segments / 64.0) * cyc_a / (cus * SIMDS_PER_CU * NOMINAL_CLOCK_GHZ * 1e9)
+            out["all_pairs"] = {"value": round(sta.segments / (mean_a * 1e-3) / 1e6, 3), "unit": "Mrays/s", "kernel_ms": round(mean_a, 3), "kernel_ms_min": round(min(msa), 3),
+                                "tiles_evaluated_per_wave_iteration": round(sta.mx_tiles / max(sta.wave_iterations, 1), 3),
+                                "bound_ms_per_launch": round(tb_a * 1e3, 3), "frac": round(tb_a / (mean_a * 1e-3), 4), "same_image": True,
+                                "note": "MIRT_FLAG_ALL_PAIRS: the same kernel without the tile cull - every (ray, sphere) pair through the matrix pipe, as in round 2; same image bit for bit"}
+            del banda
         if world == 1 and kind == 1 and not args.no_extras:
             # the same frame with the broad phase on the vector ALU (MIRT_FLAG_VALU_BROAD): the kernel the VALU roofline describes directly
             o3 = cam.opts(precision=32, seed=args.seed, strip_rows=S, part_index=0, part_count=1, flags=abi.FLAG_COMPACT_ROWS | abi.FLAG_VALU_BROAD)

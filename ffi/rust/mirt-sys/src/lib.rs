@@ -31,6 +31,7 @@ pub const MIRT_FLAG_BVH: u32 = 2;
 pub const MIRT_FLAG_VALU_BROAD: u32 = 4;
 pub const MIRT_FLAG_DEFER_STATS: u32 = 8;
 pub const MIRT_FLAG_MX_SMALL: u32 = 16; // tuning / test switch, image-neutral
+pub const MIRT_FLAG_ALL_PAIRS: u32 = 32; // matrix-pipe kernels: no tile cull (measurements), image-neutral
 pub const MIRT_STATIC_SCRATCH_BYTES: u64 = 128 << 20; // the device array behind mirt_render_device_static
 
 #[repr(C)]
@@ -131,6 +132,7 @@ pub struct mirt_stats {
     pub kernel_ms: f64,
     pub tree_segments: u64,
     pub resolve_ms: f64, // of kernel_ms (K2 + K2b): the resolve kernel alone
+    pub mx_tiles: u64,   // (wave, tile of 32 spheres) evaluations of the matrix-pipe kernels: what the tile cull left
 }
 
 pub const MIRT_NODE_MAX_DEVICES: usize = 16;
@@ -170,7 +172,7 @@ const _: () = assert!(std::mem::size_of::<mirt_material>() == 64);
 const _: () = assert!(std::mem::size_of::<mirt_sphere>() == 64);
 const _: () = assert!(std::mem::size_of::<mirt_camera>() == 192);
 const _: () = assert!(std::mem::size_of::<mirt_opts>() == 48);
-const _: () = assert!(std::mem::size_of::<mirt_stats>() == 80);
+const _: () = assert!(std::mem::size_of::<mirt_stats>() == 88);
 const _: () = assert!(std::mem::size_of::<mirt_node_stats>() == 304);
 
 extern "C" {

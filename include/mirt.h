@@ -135,6 +135,11 @@ typedef enum mirt_precision {
 /* Brute-force loop: take the matrix-pipe broad phase also for scenes below its size threshold (24 spheres), where the
  * vector-ALU loop is faster.  A tuning / test switch; the image does not depend on it. */
 #define MIRT_FLAG_MX_SMALL 16u
+/* Matrix-pipe brute-force loop, resident scenes (<= 1024 spheres): test every (ray, sphere) pair.  By default the kernel first
+ * tests, with the same contraction and margins, a ball around each tile of 32 spheres (the spheres are kept in a spatial order)
+ * and skips the tiles that no ray of the wave can touch - the (id, t) of every ray, hence the image, is the same bit for bit;
+ * mirt_stats.mx_tiles tells how many tiles were evaluated.  The flag switches the cull off (measurements: the all-pairs rate). */
+#define MIRT_FLAG_ALL_PAIRS 32u
 
 /* Which rows a call renders: rows are grouped in strips of `strip_rows`; strip s is owned when
  * s % part_count == part_index (interleaved strips).  part_count <= 1 = whole image.
@@ -172,6 +177,8 @@ typedef struct mirt_stats {
     uint64_t tree_segments;   /* of `segments`: traced through the bounding-volume tree (MIRT_FLAG_BVH);  */
                               /* those are not counted in *_tests                                          */
     double resolve_ms;        /* of kernel_ms: the resolve kernel K2b alone (K2 = kernel_ms - resolve_ms) */
+    uint64_t mx_tiles;        /* matrix-pipe kernels: (wave, tile of 32 spheres) evaluations actually made - the tile cull */
+                              /* skips tiles no ray of a wave can touch; wave_iterations x tiles without it (0: other kernels) */
 } mirt_stats;
 
 typedef struct mirt_scene mirt_scene; /* opaque: device-resident flattened scene */

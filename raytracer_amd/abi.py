@@ -13,6 +13,7 @@ FLAG_COMPACT_ROWS = 1
 FLAG_BVH = 2  # closest hit through the bounding-ball tree (f32 only); same image bit for bit
 FLAG_DEFER_STATS = 8  # _device render calls: return at once, mirt_render_wait() collects the statistics
 FLAG_VALU_BROAD = 4  # f32 brute force: broad phase on the vector ALU instead of the matrix pipe; same image bit for bit
+FLAG_ALL_PAIRS = 32  # matrix-pipe kernels: no tile cull, every (ray, sphere) pair is tested; same image bit for bit
 FLAG_MX_SMALL = 16  # matrix-pipe broad phase also for scenes below its size threshold (tests, tuning); same image bit for bit
 STATIC_SCRATCH_BYTES = 128 << 20  # MIRT_STATIC_SCRATCH_BYTES: the device array behind mirt_render_device_static
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
@@ -103,6 +104,7 @@ class MirtStats(C.Structure):
         ("kernel_ms", C.c_double),  # K2 + K2b
         ("tree_segments", C.c_uint64),
         ("resolve_ms", C.c_double),  # of kernel_ms: K2b alone
+        ("mx_tiles", C.c_uint64),  # (wave, tile) evaluations of the matrix-pipe kernels: what the tile cull left
     ]
 
     def asdict(self):

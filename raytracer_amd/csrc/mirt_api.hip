@@ -60,6 +60,7 @@ struct mirt_scene {
     MxSet mx32, mx64;             /* balls around the f32 spheres (what the f32 kernels test) and around the f64 ones */
     mutable uint4* SM = nullptr;  /* operands and scale of the call being launched */
     mutable float mx_scale = 1.f;
+    mutable uint32_t mx_cull = 0; /* this call may skip tiles by the top tile (resident scenes, not MIRT_FLAG_ALL_PAIRS) */
     DevStats* stats = nullptr; /* one per scene: launches on one scene handle are ordered one after the other (ev_busy) */
     mutable std::vector<void*> allocs; /* everything freed with the scene (mutable: operand copies are made on first use) */
     /* render workspace (per-item partial sums; f64: per-lane attenuation stacks), grown on demand and kept until the scene
@@ -372,16 +373,50 @@ static int mx_ensure(const mirt_scene* s, const mirt_scene::MxSet& set, int e) {
         h = (_Float16)x;
         l = (_Float16)(x - (double)h);
     };
-    for (size_t T = 0; T < ntiles; ++T)
+    /* The top tile (slot `ntiles` of the operand array, resident scenes only: <= 32 tiles): row k holds a ball around ALL the
+     * balls of tile k, tested by the same contraction with the same margins - if the exact discriminant of any sphere of
+     * tile k can be >= 0 the real line meets that sphere's ball, hence the tile's, hence row k's test passes - so a tile whose
+     * row no ray of the wave passes can be skipped whole (trace_mx).  A tile ball that leaves the operand range (|C| + R > 64
+     * in scaled units) is marked "always" (w = -60000: q > 0 for every ray), an empty tile "never" (the dummy record). */
+    std::vector<MxBall> top;
+    if (ntiles <= 32) {
+        top.assign(32, MxBall{{0, 0, 0}, 0, false});
+        const size_t per = ntiles <= 16 ? 16 : 32; /* slots per row of the top tile: scenes of <= 16 tiles get a ball per HALF tile */
+        for (size_t T = 0; T < (balls.size() + per - 1) / per; ++T) {
+            double lo3[3] = {1e300, 1e300, 1e300}, hi3[3] = {-1e300, -1e300, -1e300};
+            bool any = false;
+            for (size_t i = per * T; i < std::min(balls.size(), per * T + per); ++i)
+                if (balls[i].real) {
+                    any = true;
+                    for (int a = 0; a < 3; ++a) { lo3[a] = std::min(lo3[a], balls[i].M[a] - balls[i].rho); hi3[a] = std::max(hi3[a], balls[i].M[a] + balls[i].rho); }
+                }
+            if (!any) continue;
+            MxBall t{{0.5 * (lo3[0] + hi3[0]), 0.5 * (lo3[1] + hi3[1]), 0.5 * (lo3[2] + hi3[2])}, 0, true};
+            for (size_t i = per * T; i < std::min(balls.size(), per * T + per); ++i)
+                if (balls[i].real) {
+                    const double dx = balls[i].M[0] - t.M[0], dy = balls[i].M[1] - t.M[1], dz = balls[i].M[2] - t.M[2];
+                    t.rho = std::max(t.rho, std::sqrt(dx * dx + dy * dy + dz * dz) + balls[i].rho);
+                }
+            t.rho = t.rho * (1.0 + 1e-9) + 1e-300;
+            top[T] = t;
+        }
+    }
+    for (size_t T = 0; T < ntiles + (top.empty() ? 0 : 1); ++T)
         for (uint32_t row = 0; row < 32; ++row) {
+            const bool is_top = T == ntiles;
+            const std::vector<MxBall>& src = is_top ? top : balls;
             const uint32_t sub = (row / 4) % 2, r = (row % 4) + 4 * (row / 8);
-            const size_t idx = 32 * T + 16 * sub + r;
+            const size_t idx = (is_top ? 0 : 32 * T) + 16 * sub + r;
             _Float16 sv[32];
             for (int k = 0; k < 32; ++k) sv[k] = (_Float16)0.f;
             sv[27] = sv[28] = sv[29] = (_Float16)1.0f;
             sv[30] = (_Float16)60000.0f; /* dummy: q = c0 - 60000 < 0 for every admissible ray (c0 <= 0) */
-            if (idx < balls.size() && balls[idx].real) {
-                const MxBall& b = balls[idx];
+            if (is_top && idx < src.size() && src[idx].real &&
+                !((std::sqrt(src[idx].M[0] * src[idx].M[0] + src[idx].M[1] * src[idx].M[1] + src[idx].M[2] * src[idx].M[2]) + src[idx].rho) * sc <= 64.0)) {
+                sv[30] = (_Float16)-50000.0f; /* out of the operand range: q = c0 + 50000 > 0 for every ray in range (c0 >= -36000) and for the
+                                                 lanes marked "origin out of range" (c0 = +60000), < 0 for the lanes without a ray (c0 = -60000) */
+            } else if (idx < src.size() && src[idx].real) {
+                const MxBall& b = src[idx];
                 const double m[3] = {b.M[0] * sc, b.M[1] * sc, b.M[2] * sc}; /* exact: power of two */
                 const double M2 = m[0] * m[0] + m[1] * m[1] + m[2] * m[2];
                 static const int pi[6] = {0, 1, 2, 0, 0, 1}, pj[6] = {0, 1, 2, 1, 2, 2}; /* xx yy zz xy xz yz */
@@ -415,7 +450,7 @@ template <class R> static DevScene<R> dev_scene(const mirt_scene* s, const Scene
     d.n_materials = s->n_materials;
     d.bvh = s->bvh; d.bvh_S = s->bvh_S; d.bvh_idx = s->bvh_idx; d.bvh_root = s->bvh_root;
     d.bvh_n_nodes = s->bvh_n_nodes; d.bvh_n_recs = s->bvh_n_recs; d.bvh_depth = s->bvh_depth;
-    d.SM = s->SM; d.mx_scale = s->mx_scale;
+    d.SM = s->SM; d.mx_scale = s->mx_scale; d.mx_cull = s->mx_cull;
     d.dbg = s->stats ? &s->stats->broad_misses : nullptr;
     return d;
 }
@@ -544,6 +579,13 @@ static int occupancy_of(const void* fn, int block) {
     return per_cu;
 }
 
+/* Tile cull of the matrix-pipe kernels (trace_mx): 0 = every tile is evaluated (MIRT_FLAG_ALL_PAIRS; scenes beyond the LDS, whose
+ * top tile does not exist; scenes of one or two tiles, where the extra tile costs more than it can save), 2 = the top tile holds
+ * a ball per HALF tile (scenes of <= 16 tiles), 1 = a ball per tile - exactly as mx_ensure lays the top tile out */
+static uint32_t mx_cull_mode(const mirt_scene* s, bool mx, const mirt_opts* o) {
+    if (!mx || (o->flags & MIRT_FLAG_ALL_PAIRS) || s->n > MIRT_LDS_RECORDS || s->n <= 64u) return 0u;
+    return s->n <= 512u ? 2u : 1u;
+}
 /* the two render kernels behind one name */
 static const void* render_fn(double, int bvh) { return bvh == 3 ? (const void*)render_kernel_f64_mx : (const void*)render_kernel_f64<2>; }
 static const void* render_fn(float, int bvh) { return bvh == 4 ? (const void*)render_kernel_f32_tiny : bvh == 6 ? (const void*)render_kernel_f32_mx_ring : bvh == 5 ? (const void*)render_kernel_f32_mx<MxLdsSmall> : bvh == 3 ? (const void*)render_kernel_f32_mx<MxLds> : bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
@@ -710,6 +752,49 @@ static int static_scratch_ptr(int device, unsigned char** out) { /* the calling 
     return MIRT_OK;
 }
 
+/* k-d order of order[lo, hi) (indices into the description's spheres): split at the median of the axis along which the centres
+ * (mid-shutter) spread most, with the cut placed on a tile boundary of the final array (slot numbers that are multiples of
+ * 32; `lo` sits at slot `slot_lo`), until a range fits one tile.  Deterministic (ties by index). */
+static void spatial_order(const mirt_scene_desc* d, std::vector<uint32_t>& order, size_t lo, size_t hi, size_t slot_lo) {
+    if (hi - lo <= 1) return;
+    const size_t slot_hi = slot_lo + (hi - lo);
+    if (slot_lo / 16 == (slot_hi - 1) / 16) return; /* one half tile: the finest grain the top tile can tell apart */
+    auto centre = [&](uint32_t i, int a) {
+        const mirt_sphere& sp = d->spheres[i];
+        return sp.moving ? 0.5 * (sp.center0[a] + sp.center1[a]) : sp.center0[a];
+    };
+    /* the axis of the widest spread - between the 10th and the 90th percentile of the centres, not between the extremes: one
+     * huge ground sphere 1000 units below the rest must not make "height" the axis everything is split along */
+    double spread[3] = {0, 0, 0};
+    {
+        std::vector<double> v(hi - lo);
+        for (int a = 0; a < 3; ++a) {
+            for (size_t k = lo; k < hi; ++k) { const double c = centre(order[k], a); v[k - lo] = c == c ? c : 0.0; }
+            const size_t p10 = v.size() / 10, p90 = v.size() - 1 - v.size() / 10;
+            std::nth_element(v.begin(), v.begin() + p10, v.end());
+            const double lo_v = v[p10];
+            std::nth_element(v.begin(), v.begin() + p90, v.end());
+            spread[a] = v[p90] - lo_v;
+        }
+    }
+    int ax = 0;
+    for (int a = 1; a < 3; ++a) if (spread[a] > spread[ax]) ax = a;
+    /* the tile boundary nearest to the middle of the range (inside one tile: the half-tile boundary) */
+    const size_t mid_slot = (slot_lo + slot_hi) / 2;
+    const size_t grain = slot_lo / 32 == (slot_hi - 1) / 32 ? 16 : 32;
+    size_t cut_slot = (mid_slot + grain / 2) / grain * grain;
+    if (cut_slot <= slot_lo) cut_slot += grain;
+    if (cut_slot >= slot_hi) cut_slot -= grain;
+    if (cut_slot <= slot_lo || cut_slot >= slot_hi) return;
+    const size_t mid = lo + (cut_slot - slot_lo);
+    std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi, [&](uint32_t x, uint32_t y) {
+        const double cx = centre(x, ax), cy = centre(y, ax);
+        return cx < cy || (cx == cy && x < y) || (cy != cy && cx == cx); /* NaN centres last */
+    });
+    spatial_order(d, order, lo, mid, slot_lo);
+    spatial_order(d, order, mid, hi, cut_slot);
+}
+
 extern "C" {
 
 int mirt_abi_version(void) { return (int)MIRT_ABI_VERSION; }
@@ -768,16 +853,39 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cus = prop.multiProcessorCount;
     }
     if (d->n_spheres > 0xFFFFFF00u) { delete s; return fail(MIRT_ERR_TOO_LARGE, "too many spheres"); }
-    /* statics first, each section in insertion order and padded to a whole broad-phase group */
+    /* statics first, each section padded to a whole broad-phase group.  Within a section the spheres are put in a SPATIAL
+     * order (spatial_order below): the matrix-pipe kernels test a ball around each tile of 32 consecutive slots first and skip
+     * the tiles no ray of the wave can touch, which pays only if a tile's spheres lie together.  The order is internal: hit ids
+     * are the description's indices (orig_id), ties in t go to the lower hit id, so the image does not depend on it. */
     std::vector<uint32_t> order;
     order.reserve((size_t)d->n_spheres + MIRT_GROUP + 32);
+    uint32_t n_stat = 0;
+    bool neg_zero = false; /* a static centre component of -0.0 (see below) */
     for (uint32_t i = 0; i < d->n_spheres; ++i)
-        if (!d->spheres[i].moving) order.push_back(i);
-    s->true_static = (uint32_t)order.size();
-    while (order.size() % MIRT_GROUP) order.push_back(0xFFFFFFFFu);
-    s->n_static = (uint32_t)order.size();
-    for (uint32_t i = 0; i < d->n_spheres; ++i)
-        if (d->spheres[i].moving) order.push_back(i);
+        if (!d->spheres[i].moving) {
+            ++n_stat;
+            for (int a = 0; a < 3; ++a) neg_zero = neg_zero || (d->spheres[i].center0[a] == 0.0 && std::signbit(d->spheres[i].center0[a]));
+        }
+    s->true_static = n_stat;
+    /* Scenes that fit the LDS (where the tile cull works) and hold both kinds: ONE section, statics among the movings, so that
+     * every tile is a compact patch of the scene instead of the statics' tiles spanning all of it.  The kernels then take every
+     * sphere as moving with a zero displacement: c0 + tm * 0 is c0 exactly in both precisions (the one exception, a -0.0
+     * component that the sum would turn into +0.0, keeps such a scene in two sections). */
+    const bool one_section = n_stat > 0 && n_stat < d->n_spheres && d->n_spheres <= MIRT_LDS_RECORDS - 2 * MIRT_GROUP && !neg_zero;
+    if (one_section) {
+        for (uint32_t i = 0; i < d->n_spheres; ++i) order.push_back(i);
+        s->n_static = 0;
+        spatial_order(d, order, 0, order.size(), 0);
+    } else {
+        for (uint32_t i = 0; i < d->n_spheres; ++i)
+            if (!d->spheres[i].moving) order.push_back(i);
+        spatial_order(d, order, 0, order.size(), 0);
+        while (order.size() % MIRT_GROUP) order.push_back(0xFFFFFFFFu);
+        s->n_static = (uint32_t)order.size();
+        for (uint32_t i = 0; i < d->n_spheres; ++i)
+            if (d->spheres[i].moving) order.push_back(i);
+        spatial_order(d, order, s->n_static, order.size(), s->n_static);
+    }
     /* ... and the whole array to whole 32-sphere tiles of the matrix-pipe broad phase (a multiple of the 16-record groups
      * of trace_cons and of MIRT_GROUP): a lane whose operands say "every record of this tile is a candidate" (origin out of
      * range, NaN) then meets a dummy record in every slot up to the end of the last tile, in HBM and in the LDS copies */
@@ -918,6 +1026,7 @@ int mirt_primary_hits_device(const mirt_scene* s, const mirt_camera* cam, const 
     int mx_e = 0;
     const bool mx = use_mx(s, cam, o, &mx_e);
     if (mx && (rc = mx_ensure(s, mx_set(s, o), mx_e))) return rc;
+    s->mx_cull = mx_cull_mode(s, mx, o);
     return o->precision == MIRT_F64 ? launch_primary(s, s->f64, cam, part, d_id, d_t, st, mx)
                                     : launch_primary(s, s->f32, cam, part, d_id, d_t, st, (o->flags & MIRT_FLAG_BVH) != 0, mx);
 }
@@ -1005,6 +1114,7 @@ static void fill_stats(const mirt_scene* s, uint32_t flags, const DevStats& h, f
     stats->wave_iterations = h.wave_iters;
     stats->nan_pixels = h.nan_pixels;
     stats->kernel_ms = ms;
+    stats->mx_tiles = h.mx_tiles;
     stats->resolve_ms = (resolve_ms > 0.f && resolve_ms <= ms) ? resolve_ms : 0.0; /* a call that launched nothing leaves the mid event where an earlier call put it */
 }
 int mirt_render_wait(const mirt_scene* s, mirt_stats* stats) {
@@ -1047,6 +1157,7 @@ static int render_impl(const mirt_scene* s, const mirt_camera* cam, const mirt_o
     int mx_e = 0;
     const bool mx = use_mx(s, cam, o, &mx_e);
     if (mx && (rc = mx_ready(s, mx_set(s, o), mx_e, !use_static))) return rc; /* before the timed region: the first call at a new scale uploads operands */
+    s->mx_cull = mx_cull_mode(s, mx, o); /* as mx_ensure lays the top tile out */
     /* where the launch keeps its counters, partial sums and attenuation stacks */
     Workspace ws{s->stats, &s->partial, &s->partial_bytes, &s->att, &s->att_bytes, nullptr, 0};
     if (use_static) {

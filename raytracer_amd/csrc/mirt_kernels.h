@@ -122,6 +122,7 @@ struct DevStats { /* device-side counters, one atomic per wave at kernel end */
     unsigned long long segments, narrow, wave_iters, nan_pixels;
     unsigned int queue_head; /* next unclaimed work item of the running render launch */
     unsigned int _pad;
+    unsigned long long mx_tiles; /* matrix-pipe kernels: (wave, tile of 32 spheres) evaluations, i.e. what the tile cull left of wave_iters x tiles */
     unsigned long long phase_cycles[6]; /* diagnostic builds only (MIRT_PHASE_TIMING) */
     unsigned long long broad_misses;    /* diagnostic builds only (MIRT_VERIFY_BROAD): must be 0 */
     /* diagnostic builds only (MIRT_PHASE_TIMING), in s_memrealtime ticks (100 MHz): */
@@ -590,7 +591,7 @@ template <uint32_t RECORDS, uint32_t MATS, uint32_t ENT_WORDS = 12, uint32_t PAI
      * PAIRS (ray lane, sphere) pairs per wave, one (t, hit id, sphere) result slot per lane, the hit ids of the sorted slots */
     static constexpr uint32_t PAIR_CAP = PAIRS;
     static_assert(PAIRS == 0 || (PAIRS >= 128 && (PAIRS & (PAIRS - 1)) == 0 && RECORDS <= 1024), "pair ring: a power of two >= 128; 10-bit sphere index");
-    uint4 SM[RECORDS * 4]; /* 2 x 64 x 16 B per tile of 32 spheres */
+    uint4 SM[RECORDS * 4 + 128]; /* 2 x 64 x 16 B per tile of 32 spheres, + the top tile (the balls around the tiles) behind the last one */
     float4 A[RECORDS];
     float4 B[RECORDS];
     unsigned long long slot[PAIRS ? MIRT_F32_WAVES : 1][PAIRS ? MIRT_WAVE : 1];
@@ -614,7 +615,7 @@ template <uint32_t RECORDS, uint32_t MATS, uint32_t ENT_WORDS = 12, uint32_t PAI
         }
         if (res) {
             const uint32_t ntiles = (sc.n + 31) / 32;
-            for (uint32_t i = threadIdx.x; i < ntiles * 128; i += blockDim.x) SM[i] = sc.SM[i];
+            for (uint32_t i = threadIdx.x; i < (ntiles + 1u) * 128; i += blockDim.x) SM[i] = sc.SM[i]; /* + the top tile */
             for (uint32_t i = threadIdx.x; i < sc.n; i += blockDim.x) {
                 A[i] = sc.A[i];
                 B[i] = sc.B[i];
@@ -634,20 +635,20 @@ template <uint32_t RECORDS, uint32_t MATS, uint32_t ENT_WORDS = 12, uint32_t PAI
 #define MIRT_MX_PAIRS 128 /* 0: every lane walks its own candidates (the narrow phase of rounds 1 and 2) */
 #endif
 typedef MxLdsT<MIRT_MX_SMALL_RECORDS, 512u, MIRT_MX_SMALL_ENT, MIRT_MX_PAIRS> MxLdsSmall; /* 32 + 8 + 8 + (8 + 4 + 1) + 1 + 56 + 36 KB; 7 entries per lane: 13.58 -> 13.53 ms against 6 */
-typedef MxLdsT<MIRT_LDS_RECORDS, 184u> MxLds;            /* 64 + 16 + 16 + 2 + 48 + 12.9 KB */
+typedef MxLdsT<MIRT_LDS_RECORDS, 155u> MxLds;            /* 66 + 16 + 16 + 2 + 48 + 10.9 KB */
 static_assert(sizeof(MxLds) <= 160u * 1024u && sizeof(MxLdsSmall) <= 160u * 1024u, "MxLds layouts must fit the CU's LDS");
 /* f64 kernels (256-thread blocks): only the operands and the entry lists; the exact f64 records come through L2 */
 #define MIRT_MX64_RECORDS 512u /* three blocks per CU: 32 KB of operands + 12 KB of entry lists each */
 struct MxLds64 {
     static constexpr bool GEOM_LDS = false;
     static constexpr uint32_t LDS_ENT_CAP = MIRT_ENT_CAP;
-    uint4 SM[MIRT_MX64_RECORDS * 4];
+    uint4 SM[MIRT_MX64_RECORDS * 4 + 128];
     uint32_t ent[MIRT_WAVES_PER_BLOCK][MIRT_ENT_CAP][MIRT_WAVE];
     __device__ inline bool fill(const DevScene<double>& sc) {
         const bool res = sc.n <= MIRT_MX64_RECORDS;
         if (res) {
             const uint32_t ntiles = (sc.n + 31) / 32;
-            for (uint32_t i = threadIdx.x; i < ntiles * 128; i += blockDim.x) SM[i] = sc.SM[i];
+            for (uint32_t i = threadIdx.x; i < (ntiles + 1u) * 128; i += blockDim.x) SM[i] = sc.SM[i]; /* + the top tile */
         }
         __syncthreads();
         return res;
@@ -841,7 +842,7 @@ __device__ inline void narrow_drain(const DevScene<float>& sc, LDS& L, uint32_t 
  * phase is the exact f64 test. */
 template <class R, class LDS, bool RES>
 __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint32_t lane, bool active, const RayT<R>& ray, R tmin,
-                                Closest<R>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+                                Closest<R>& best, uint32_t& narrow_count, PhaseTimer& pt, uint32_t& tiles_done) {
     best.t = (R)INFINITY;
     best.idx = 0xFFFFFFFFu;
     const RayA<R> a_true = ray_a(ray.d);
@@ -860,6 +861,38 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
     constexpr bool BALANCED = RES && sizeof(R) == 4 && mx_pair_cap<LDS>::value > 0;
     uint32_t ring_head = 0, ring_tail = 0;
     if constexpr (BALANCED) L.slot[w][lane] = MIRT_KEY_NONE;
+    /* ---- tile cull (resident scenes): which tiles can ANY ray of this wave touch?  The top tile behind the last one holds a
+     * ball around each tile's balls; one pass of the same contraction over it gives every lane the tiles its ray may meet, the
+     * wave ORs them, and the loop below skips the rest.  A skipped tile has no candidate for any lane (its ball test is as
+     * conservative as the sphere tests, mx_ensure), so the entry lists - and every (id, t) - are what the full loop gives.
+     * The lanes of a wave hold chunks of neighbouring pixels and their scattered rays start next to each other: with the
+     * spheres in a spatial order most tiles drop out. */
+    uint32_t need = 0xFFFFFFFFu;
+    if (RES && sc.mx_cull) {
+        const mirt_h8 a0 = SM[ntiles * 128 + lane], a1 = SM[ntiles * 128 + 64 + lane];
+        const mirt_f16v zero = {};
+        uint32_t mx = 0, my = 0;
+        mirt_f16v qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bx0, zero, 0, 0, 0);
+        mirt_f16v qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, by0, zero, 0, 0, 0);
+        qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bx1, qx, 0, 0, 0);
+        qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, by1, qy, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = __builtin_amdgcn_alignbit(mx, __float_as_uint(qx[r]), 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my = __builtin_amdgcn_alignbit(my, __float_as_uint(qy[r]), 31);
+        auto sw = __builtin_amdgcn_permlane32_swap(mx, my, false, false);
+        /* sw[0]: this lane's ray against rows 0..15 of the top tile (bit 15 - k set = row k ruled out), sw[1]: rows 16..31;
+         * reversed and complemented: bit k set = the ray may touch the ball of row k */
+        uint32_t mine = __builtin_bitreverse32((~sw[0] << 16) | (~sw[1] & 0xFFFFu));
+        mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x111, 0xF, 0xF, false); /* OR over the wave, as wave_scan_incl adds */
+        mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x112, 0xF, 0xF, false);
+        mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x114, 0xF, 0xF, false);
+        mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x118, 0xF, 0xF, false);
+        mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x142, 0xA, 0xF, false);
+        mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x143, 0xC, 0xF, false);
+        need = (uint32_t)__builtin_amdgcn_readlane((int)mine, 63);
+        ++tiles_done; /* the top tile is a tile's worth of work too */
+    }
     while (t < ntiles) { /* one pass unless some lane's entry list fills up */
         prio_broad();
         uint32_t cnt = 0;
@@ -869,6 +902,26 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
         bool flush = false;
         for (; t < tlimit && !flush; ++t) {
             mirt_h8 a0, a1;
+            /* mx_cull 1: row t is the ball of tile t; 2 (scenes of <= 16 tiles): rows 2t and 2t + 1 are the balls of its two halves */
+            if (RES && !(sc.mx_cull == 2u ? (need >> (2u * t)) & 3u : (need >> t) & 1u)) { /* wave-uniform: no ray of the wave can touch this tile */
+#ifdef MIRT_VERIFY_BROAD
+                for (uint32_t k_ = 0; k_ < 32; ++k_) { /* ... then no sphere of it may have an exact discriminant >= 0 */
+                    const uint32_t i_ = t * 32 + k_;
+                    if (i_ >= sc.n) break;
+                    typename Vec4<R>::type sa_ = sc.A[i_];
+                    V3<R> C_ = {sa_.x, sa_.y, sa_.z};
+                    if (i_ >= sc.n_static) {
+                        typename Vec4<R>::type sb_ = sc.B[i_];
+                        C_ = center_at(C_, V3<R>{sb_.x, sb_.y, sb_.z}, ray.tm);
+                    }
+                    R hh_, dd_;
+                    disc(C_ - ray.o, ray.d, a_true, sa_.w, hh_, dd_);
+                    if (active && dd_ >= (R)0.0) atomicAdd(sc.dbg, 1ull);
+                }
+#endif
+                continue;
+            }
+            ++tiles_done;
             if (RES) {
                 a0 = SM[t * 128 + lane];
                 a1 = SM[t * 128 + 64 + lane];
@@ -1372,6 +1425,7 @@ template <bool RES, class LDS = MxLds> struct TracerF32Mx {
     const DevScene<float>& sc;
     LDS& L;
     uint32_t w;
+    uint32_t tiles = 0; /* tiles of 32 spheres this wave ran through the matrix pipe (wave-uniform): what the tile cull left */
     __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
         const unsigned long long live = __ballot(active);
         if ((uint32_t)__popcll(live) <= MIRT_FEW_LANES) {
@@ -1379,7 +1433,7 @@ template <bool RES, class LDS = MxLds> struct TracerF32Mx {
             else trace_few(sc, GeomGlobal<float>{sc}, lane, live, ray, tmin, best, nc);
             pt.stamp(PH_NARROW);
         } else {
-            trace_mx<float, LDS, RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
+            trace_mx<float, LDS, RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt, tiles);
         }
     }
     __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const {
@@ -1403,7 +1457,9 @@ template <class LDS> struct TracerF32MxRing {
     const DevScene<float>& sc;
     LDS& L;
     uint32_t w;
+    uint32_t tiles = 0;
     __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
+        if (__ballot(active) != 0ull) tiles += (sc.n + 31u) / 32u;
         trace_mx_ring<LDS>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
     }
     __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const { return make_hit(sc, GeomGlobal<float>{sc}, c, ray); }
@@ -1421,8 +1477,9 @@ template <bool RES> struct TracerF64Mx {
     const DevScene<double>& sc;
     MxLds64& L;
     uint32_t w;
+    uint32_t tiles = 0;
     __device__ inline void closest(uint32_t lane, bool active, const RayT<double>& ray, double tmin, Closest<double>& best, uint32_t& nc, PhaseTimer& pt) {
-        trace_mx<double, MxLds64, RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
+        trace_mx<double, MxLds64, RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt, tiles);
     }
     __device__ inline Hit<double> hit(const Closest<double>& c, const RayT<double>& ray) const { return make_hit(sc, GeomGlobal<double>{sc}, c, ray); }
     __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }
@@ -1719,6 +1776,9 @@ struct RenderParams {
 /* T::LOCKSTEP, where a tracer declares it */
 template <class T, class = void> struct tracer_lockstep { static constexpr bool value = false; };
 template <class T> struct tracer_lockstep<T, decltype((void)T::LOCKSTEP)> { static constexpr bool value = T::LOCKSTEP; };
+/* tr.tiles, where a tracer counts them */
+template <class T, class = void> struct tracer_tiles { static __device__ inline uint32_t get(const T&) { return 0u; } };
+template <class T> struct tracer_tiles<T, decltype((void)((T*)nullptr)->tiles)> { static __device__ inline uint32_t get(const T& t) { return t.tiles; } };
 
 template <class T>
 __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, const DevCamera<typename T::Real>& cam, const DevPart& part,
@@ -1963,6 +2023,8 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
         atomicAdd(&stats->segments, (unsigned long long)s1);
         atomicAdd(&stats->narrow, (unsigned long long)s2);
         atomicAdd(&stats->wave_iters, (unsigned long long)n_iter);
+        const uint32_t nt = tracer_tiles<T>::get(tr);
+        if (nt) atomicAdd(&stats->mx_tiles, (unsigned long long)nt);
     }
 }
 

@@ -36,7 +36,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(abi.MirtSceneDesc) == 16 + 32
     assert C.sizeof(abi.MirtCamera) == 7 * 24 + 8 + 16
     assert C.sizeof(abi.MirtOpts) == 48
-    assert C.sizeof(abi.MirtStats) == 80
+    assert C.sizeof(abi.MirtStats) == 88
 
 
 def test_host_only_helpers():

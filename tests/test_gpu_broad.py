@@ -2,6 +2,8 @@
 for resident scenes inside the f16 range, split-f16 operands through v_mfma_f32_32x32x16_f16) - must select supersets of
 the exact candidates, i.e. give the same (id, t) for every ray: maps bit-exact against the f32 oracle and against each
 other, rendered images bit-identical, and the host must fall back to the vector ALU where the operands would not fit."""
+import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -317,3 +319,77 @@ def test_fuzz_all_front_ends_against_the_oracle():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_maps.py"), "4000", "8"], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode == 0 and "mismatching maps: 0" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
+
+
+# ---- round 3: the tile cull of the matrix-pipe kernels ------------------------------------------------------------------------
+def _cull_scenes():
+    rng = np.random.default_rng(5)
+    mats = [Lambertian.new((0.6, 0.5, 0.4), 0.9), Metal.new((0.8, 0.8, 0.9), 0.1), Dielectric.new(1.5)]
+    out = [("bench scene", presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(192, 4, 30))]
+    # two far-apart clusters and a huge ground: most tiles are out of every ray's way
+    sc = Scene()
+    sc.add(Sphere.new_static(2000.0, (0.0, -2000.0, 0.0), mats[0]))
+    for c0 in ((-40.0, 1.0, 0.0), (40.0, 1.0, 5.0)):
+        for k in range(150):
+            c = np.array(c0) + rng.uniform(-6, 6, 3) * np.array([1.0, 0.1, 1.0])
+            m = mats[k % 3]
+            if k % 4 == 0:
+                sc.add(Sphere.new(0.3, tuple(c), tuple(c + rng.uniform(-0.3, 0.3, 3)), m))
+            else:
+                sc.add(Sphere.new_static(0.3, tuple(c), m))
+    sc.build_bvh()
+    out.append(("two clusters", sc, Camera.build((0.0, 6.0, 60.0), (0.0, 0.0, 0.0), None, 160, 2.0, 3, math.radians(70.0), 60.0, 0.0, 20)))
+    # 700 spheres: the 1024-slot layout (one ball per tile); everything in one spot: nothing to cull
+    sc = Scene()
+    for k in range(700):
+        c = rng.uniform(-1, 1, 3)
+        sc.add(Sphere.new_static(0.05, tuple(c), mats[k % 3]))
+    sc.build_bvh()
+    out.append(("one spot", sc, Camera.build((0.0, 0.5, 5.0), (0.0, 0.0, 0.0), None, 96, 1.0, 3, math.radians(40.0), 5.0, 0.0, 12)))
+    # a static sphere whose centre has a -0.0 component keeps the scene in two sections (statics, movings)
+    sc = Scene()
+    sc.add(Sphere.new_static(1.0, (-0.0, 0.0, -0.0), mats[1]))
+    for k in range(80):
+        c = rng.uniform(-8, 8, 3)
+        sc.add(Sphere.new(0.4, tuple(c), tuple(c + rng.uniform(-0.5, 0.5, 3)), mats[k % 3]))
+    sc.build_bvh()
+    out.append(("negative zero", sc, Camera.build((0.0, 2.0, 20.0), (0.0, 0.0, 0.0), None, 96, 1.0, 3, math.radians(50.0), 20.0, 0.0, 12)))
+    return out
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F64])
+def test_tile_cull_changes_nothing_but_the_work(oracle, prec):
+    """Round 3: the matrix-pipe kernels test a ball around every (half) tile of spatially ordered spheres first and skip the
+    tiles no ray of a wave can touch.  Against MIRT_FLAG_ALL_PAIRS (round 2's loop): the same (id, t) for every primary ray, the
+    same frame bit for bit, fewer tiles evaluated; and the culled frame is the oracle's (f32: bit for bit)."""
+    lib = abi.load()
+    for name, sc, cam in _cull_scenes():
+        assert cam.closest_hit_kind(sc, precision=prec) in ("matrix", "f64-matrix"), name
+        ds = sc.device_scene(0)
+        res = {}
+        for flags in (0, abi.FLAG_ALL_PAIRS):
+            H, W = cam.height, cam.width
+            lin = np.empty((H, W, 3), np.float64 if prec == abi.F64 else np.float32)
+            st = abi.MirtStats()
+            o = cam.opts(precision=prec, seed=3, flags=flags)
+            abi.check(lib.mirt_render(ds.handle, C.byref(cam.pod), C.byref(o), lin.ctypes.data, None, C.byref(st)))
+            ids = np.empty((H, W), np.uint32)
+            t = np.empty((H, W), lin.dtype)
+            cam0 = Camera(cam.pod)
+            abi.check(lib.mirt_primary_hits(ds.handle, C.byref(cam0.pod), C.byref(o), ids.ctypes.data, t.ctypes.data))
+            res[flags] = (lin, ids, t, st.mx_tiles, st.wave_iterations, st.segments)
+        a, b = res[0], res[abi.FLAG_ALL_PAIRS]
+        assert np.array_equal(a[0].view(np.uint8), b[0].view(np.uint8)), name
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint8), b[2].view(np.uint8)), name
+        assert a[5] == b[5] and a[4] > 0
+        ntiles = (sc.flat.n_spheres + 31) // 32
+        # all pairs: every wave-iteration that goes through the tile loop evaluates every tile (waves down to a few live rays
+        # take trace_few instead: no tiles)
+        assert b[3] % ntiles == 0 and 0 < b[3] <= b[4] * ntiles, (name, b[3], b[4], ntiles)
+        assert a[3] <= b[3] + b[3] // ntiles, name                 # the cull adds its top tile and drops what it can
+        print(f"{name}: tiles per wave-iteration {a[3] / a[4]:.2f} of {ntiles} (+1)")
+        if name in ("bench scene", "two clusters"):
+            assert a[3] < 0.8 * b[3], (name, a[3], b[3])
+        if prec == abi.F32:
+            o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F32, seed=3, threads=8, spec_chunk=cam.pass_granularity(precision=abi.F32))
+            assert o_seg == a[5] and np.array_equal(a[0].view(np.uint32), o_lin.view(np.uint32)), name
