@@ -799,13 +799,14 @@ __device__ inline void narrow_round(const DevScene<float>& sc, LDS& L, uint32_t 
 template <class LDS>
 __device__ inline void narrow_balanced(const DevScene<float>& sc, LDS& L, uint32_t w, uint32_t lane, uint2 (*ent2)[MIRT_WAVE], uint32_t gbase, uint32_t cnt,
                                        const RayT<float>& ray, RayA<float> ra, float tmin, uint32_t& head, uint32_t& tail, uint32_t& narrow_count) {
-    uint32_t k = 0, m = 0, gi = 0;
+    uint32_t k = 0, m = 0, ga = 0, gb = 0;
     for (;;) {
         if (m == 0 && k < cnt) {
             const uint2 e = ent2[k][lane];
             ++k;
             m = (~e.x & 0xFFFFu) | (~e.y << 16);
-            gi = (gbase + (e.x >> 16)) * MIRT_CGROUP + (MIRT_CGROUP - 1);
+            ga = (gbase + (e.x >> 16)) * MIRT_CGROUP + (MIRT_CGROUP - 1);
+            gb = (gbase + (e.y >> 16)) * MIRT_CGROUP + (2 * MIRT_CGROUP - 1);
         }
         const unsigned long long have = __ballot(m != 0);
         if (have == 0ull) break;
@@ -817,7 +818,7 @@ __device__ inline void narrow_balanced(const DevScene<float>& sc, LDS& L, uint32
         if (m != 0) {
             const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
             m &= m - 1u;
-            const uint32_t idx = gi - bit + (bit >= 16u ? 32u : 0u);
+            const uint32_t idx = (bit >= 16u ? gb : ga) - bit;
             const uint32_t pos = tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(have >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)have, 0u));
             L.pairs[w][pos & (LDS::PAIR_CAP - 1u)] = (uint16_t)((lane << 10) | idx);
             ++narrow_count;
@@ -840,6 +841,25 @@ __device__ inline void narrow_drain(const DevScene<float>& sc, LDS& L, uint32_t 
  * and 6 eps ((|M|+|O|)^2 + rho^2) replaces the 32 eps of the f32 derivation (an f64 discriminant needs ~1e-15) inside the
  * same 128 eps budget; the balls behind the operands are built around the f64 spheres (mirt_scene_create).  The narrow
  * phase is the exact f64 test. */
+/* one tile: q for 32 rays x 32 spheres per chain of two MFMAs - all that is left to the vector ALU is collecting the signs.
+ * mx / my come in holding the 16-bit group numbers and leave as (group << 16) | signs: after the swap mx belongs to this lane's
+ * ray and the 16 spheres of the rows of sub 0, my to the rows of sub 1 (bit 15 - k set = sphere k of the group ruled out). */
+__device__ inline void mx_tile(const mirt_h8& a0, const mirt_h8& a1, const mirt_h8& bx0, const mirt_h8& bx1, const mirt_h8& by0, const mirt_h8& by1,
+                               uint32_t& mx, uint32_t& my) {
+    const mirt_f16v zero = {};
+    mirt_f16v qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bx0, zero, 0, 0, 0);
+    mirt_f16v qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, by0, zero, 0, 0, 0);
+    qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bx1, qx, 0, 0, 0);
+    qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, by1, qy, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = __builtin_amdgcn_alignbit(mx, __float_as_uint(qx[r]), 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) my = __builtin_amdgcn_alignbit(my, __float_as_uint(qy[r]), 31);
+    /* lanes 0-31 hold (ray l, rows of sub 0) and (ray l + 32, sub 0); lanes 32-63 (ray l - 32, sub 1) and (ray l, sub 1) */
+    auto sw = __builtin_amdgcn_permlane32_swap(mx, my, false, false);
+    mx = sw[0];
+    my = sw[1];
+}
 template <class R, class LDS, bool RES>
 __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint32_t lane, bool active, const RayT<R>& ray, R tmin,
                                 Closest<R>& best, uint32_t& narrow_count, PhaseTimer& pt, uint32_t& tiles_done) {
@@ -869,21 +889,11 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
      * spheres in a spatial order most tiles drop out. */
     uint32_t need = 0xFFFFFFFFu;
     if (RES && sc.mx_cull) {
-        const mirt_h8 a0 = SM[ntiles * 128 + lane], a1 = SM[ntiles * 128 + 64 + lane];
-        const mirt_f16v zero = {};
         uint32_t mx = 0, my = 0;
-        mirt_f16v qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bx0, zero, 0, 0, 0);
-        mirt_f16v qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, by0, zero, 0, 0, 0);
-        qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bx1, qx, 0, 0, 0);
-        qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, by1, qy, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = __builtin_amdgcn_alignbit(mx, __float_as_uint(qx[r]), 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) my = __builtin_amdgcn_alignbit(my, __float_as_uint(qy[r]), 31);
-        auto sw = __builtin_amdgcn_permlane32_swap(mx, my, false, false);
-        /* sw[0]: this lane's ray against rows 0..15 of the top tile (bit 15 - k set = row k ruled out), sw[1]: rows 16..31;
+        mx_tile(SM[ntiles * 128 + lane], SM[ntiles * 128 + 64 + lane], bx0, bx1, by0, by1, mx, my);
+        /* mx: this lane's ray against rows 0..15 of the top tile (bit 15 - k set = row k ruled out), my: rows 16..31;
          * reversed and complemented: bit k set = the ray may touch the ball of row k */
-        uint32_t mine = __builtin_bitreverse32((~sw[0] << 16) | (~sw[1] & 0xFFFFu));
+        uint32_t mine = __builtin_bitreverse32((~mx << 16) | (~my & 0xFFFFu));
         mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x111, 0xF, 0xF, false); /* OR over the wave, as wave_scan_incl adds */
         mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x112, 0xF, 0xF, false);
         mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x114, 0xF, 0xF, false);
@@ -893,31 +903,72 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
         need = (uint32_t)__builtin_amdgcn_readlane((int)mine, 63);
         ++tiles_done; /* the top tile is a tile's worth of work too */
     }
-    while (t < ntiles) { /* one pass unless some lane's entry list fills up */
+    pt.stamp(PH_OTHER); /* phase-timing build: "other" = the ray operands and the top tile */
+#ifdef MIRT_VERIFY_BROAD
+    /* the 16 spheres of group g against this lane's ray, exactly: a sphere whose discriminant is >= 0 must have its bit clear
+     * in `word` (word = all ones for a group the cull skipped) */
+    auto verify_group = [&](uint32_t g, uint32_t word) {
+        for (uint32_t k_ = 0; k_ < 16; ++k_) {
+            const uint32_t i_ = g * 16 + k_;
+            if (i_ >= sc.n) break;
+            typename Vec4<R>::type sa_ = sc.A[i_];
+            V3<R> C_ = {sa_.x, sa_.y, sa_.z};
+            if (i_ >= sc.n_static) {
+                typename Vec4<R>::type sb_ = sc.B[i_];
+                C_ = center_at(C_, V3<R>{sb_.x, sb_.y, sb_.z}, ray.tm);
+            }
+            R hh_, dd_;
+            disc(C_ - ray.o, ray.d, a_true, sa_.w, hh_, dd_);
+            if (active && dd_ >= (R)0.0 && ((word >> (15 - k_)) & 1u)) atomicAdd(sc.dbg, 1ull);
+        }
+    };
+#endif
+    /* mx_cull 2 (scenes of <= 16 tiles): row h of the top tile is the ball of HALF tile h (16 spheres), and the loop runs over
+     * the half tiles the wave needs, two at a time: the rows of sub 0 of the A operand are fetched from the first, those of sub 1
+     * from the second - a per-lane LDS address, nothing else - so a tile of which only one half is needed costs half a tile. */
+    const bool packed = RES && sc.mx_cull == 2u;
+    uint32_t rem = packed ? need : 0u;
+    while (packed ? rem != 0u : t < ntiles) { /* one pass unless some lane's entry list fills up */
         prio_broad();
         uint32_t cnt = 0;
-        const uint32_t gbase = 2 * t;
+        const uint32_t gbase = packed ? 0u : 2 * t;
+        bool flush = false;
+        if (packed) {
+            const uint32_t row = lane & 31u, from_b = (row >> 2) & 1u;
+            while (rem != 0u && !flush) {
+                const uint32_t ha = (uint32_t)__builtin_ctz(rem);
+                rem &= rem - 1u;
+                const bool two = rem != 0u;
+                const uint32_t hb = two ? (uint32_t)__builtin_ctz(rem) : ha;
+                rem &= rem - 1u; /* 0 stays 0 */
+                const uint32_t h = from_b ? hb : ha;
+                const uint32_t at = (h >> 1) * 128u + (lane & 32u) + ((row & ~4u) | ((h & 1u) << 2));
+                uint32_t mx = sub ? hb : ha, my = mx;
+                mx_tile(SM[at], SM[at + 64], bx0, bx1, by0, by1, mx, my);
+                if (!two) my |= 0xFFFFu; /* the odd one out: the rows of sub 1 were a second copy of ha */
+#ifdef MIRT_VERIFY_BROAD
+                verify_group(ha, mx);
+                if (two) verify_group(hb, my);
+#endif
+                ent2[cnt][lane] = make_uint2(mx, my);
+                cnt += ((mx & my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
+                flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull;
+                ++tiles_done;
+            }
+#ifdef MIRT_VERIFY_BROAD
+            if (rem == 0u)
+                for (uint32_t g_ = 0; g_ < 2 * ntiles; ++g_)
+                    if (!((need >> g_) & 1u)) verify_group(g_, 0xFFFFu);
+#endif
+        } else {
         uint32_t tlimit = t + 0x8000u; /* group numbers in the entries are 16 bit, relative to gbase */
         tlimit = tlimit < ntiles ? tlimit : ntiles;
-        bool flush = false;
         for (; t < tlimit && !flush; ++t) {
             mirt_h8 a0, a1;
-            /* mx_cull 1: row t is the ball of tile t; 2 (scenes of <= 16 tiles): rows 2t and 2t + 1 are the balls of its two halves */
-            if (RES && !(sc.mx_cull == 2u ? (need >> (2u * t)) & 3u : (need >> t) & 1u)) { /* wave-uniform: no ray of the wave can touch this tile */
+            if (RES && !((need >> t) & 1u)) { /* mx_cull 1: row t is the ball of tile t; wave-uniform: no ray of the wave can touch this tile */
 #ifdef MIRT_VERIFY_BROAD
-                for (uint32_t k_ = 0; k_ < 32; ++k_) { /* ... then no sphere of it may have an exact discriminant >= 0 */
-                    const uint32_t i_ = t * 32 + k_;
-                    if (i_ >= sc.n) break;
-                    typename Vec4<R>::type sa_ = sc.A[i_];
-                    V3<R> C_ = {sa_.x, sa_.y, sa_.z};
-                    if (i_ >= sc.n_static) {
-                        typename Vec4<R>::type sb_ = sc.B[i_];
-                        C_ = center_at(C_, V3<R>{sb_.x, sb_.y, sb_.z}, ray.tm);
-                    }
-                    R hh_, dd_;
-                    disc(C_ - ray.o, ray.d, a_true, sa_.w, hh_, dd_);
-                    if (active && dd_ >= (R)0.0) atomicAdd(sc.dbg, 1ull);
-                }
+                verify_group(2 * t, 0xFFFFu); /* ... then no sphere of it may have an exact discriminant >= 0 */
+                verify_group(2 * t + 1, 0xFFFFu);
 #endif
                 continue;
             }
@@ -930,36 +981,11 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
                 pre0 = SM[(t + 1) * 128 + lane];
                 pre1 = SM[(t + 1) * 128 + 64 + lane];
             }
-            const mirt_f16v zero = {};
             uint32_t mx = 2 * t - gbase + sub, my = mx;
-            /* q for 32 rays x 32 spheres per chain of two: all that is left to the vector ALU is collecting the signs */
-            mirt_f16v qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bx0, zero, 0, 0, 0);
-            mirt_f16v qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, by0, zero, 0, 0, 0);
-            qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bx1, qx, 0, 0, 0);
-            qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, by1, qy, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = __builtin_amdgcn_alignbit(mx, __float_as_uint(qx[r]), 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) my = __builtin_amdgcn_alignbit(my, __float_as_uint(qy[r]), 31);
-            /* lanes 0-31 hold (ray l, rows of sub 0) and (ray l + 32, sub 0); lanes 32-63 (ray l - 32, sub 1) and (ray l, sub 1) */
-            auto sw = __builtin_amdgcn_permlane32_swap(mx, my, false, false);
-            mx = sw[0]; /* this lane's ray, spheres 32 t .. 32 t + 15 */
-            my = sw[1]; /*                  spheres 32 t + 16 .. 32 t + 31 */
+            mx_tile(a0, a1, bx0, bx1, by0, by1, mx, my); /* mx: this lane's ray, spheres 32 t .. 32 t + 15; my: 32 t + 16 .. 32 t + 31 */
 #ifdef MIRT_VERIFY_BROAD
-            for (uint32_t k_ = 0; k_ < 32; ++k_) { /* exact discriminant >= 0 must imply the candidate bit */
-                const uint32_t i_ = t * 32 + k_;
-                if (i_ >= sc.n) break;
-                typename Vec4<R>::type sa_ = sc.A[i_];
-                V3<R> C_ = {sa_.x, sa_.y, sa_.z};
-                if (i_ >= sc.n_static) {
-                    typename Vec4<R>::type sb_ = sc.B[i_];
-                    C_ = center_at(C_, V3<R>{sb_.x, sb_.y, sb_.z}, ray.tm);
-                }
-                R hh_, dd_;
-                disc(C_ - ray.o, ray.d, a_true, sa_.w, hh_, dd_);
-                const uint32_t word_ = k_ < 16 ? mx : my;
-                if (active && dd_ >= (R)0.0 && ((word_ >> (15 - (k_ & 15u))) & 1u)) atomicAdd(sc.dbg, 1ull);
-            }
+            verify_group(2 * t, mx);
+            verify_group(2 * t + 1, my);
 #endif
             /* one 8-byte entry per tile (the list holds LDS_ENT_CAP / 2 of them): unconditional write, conditional advance
              * (cnt < LDS_ENT_CAP / 2 here: a full list flushes below) */
@@ -967,12 +993,14 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
             cnt += ((mx & my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
             flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull; /* no room for another tile */
         }
+        }
+        const bool last = packed ? rem == 0u : t >= ntiles;
         prio_other();
         pt.stamp(PH_BROAD);
         MIRT_DIAG(sc, DG_PASS, active);
         if constexpr (BALANCED) {
             narrow_balanced(sc, L, w, lane, ent2, gbase, cnt, ray, a_true, tmin, ring_head, ring_tail, narrow_count);
-            if (t >= ntiles) { /* the last pass: run what is left and collect this lane's result */
+            if (last) { /* the last pass: run what is left and collect this lane's result */
                 narrow_drain(sc, L, w, lane, ray, a_true, tmin, ring_head, ring_tail);
                 const unsigned long long ks = L.slot[w][lane];
                 if (ks != MIRT_KEY_NONE) {
@@ -984,20 +1012,21 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
         } else
         /* ---- narrow phase: as in trace_cons ---- */
         {
-            uint32_t k = 0, m = 0, gi = 0;
+            uint32_t k = 0, m = 0, ga = 0, gb = 0;
             for (;;) {
                 if (m == 0 && k < cnt) {
                     const uint2 e = ent2[k][lane];
                     ++k;
-                    m = (~e.x & 0xFFFFu) | (~e.y << 16); /* both halves of the tile: groups g and g + 1 */
-                    gi = (gbase + (e.x >> 16)) * MIRT_CGROUP + (MIRT_CGROUP - 1);
+                    m = (~e.x & 0xFFFFu) | (~e.y << 16); /* the two groups of the entry */
+                    ga = (gbase + (e.x >> 16)) * MIRT_CGROUP + (MIRT_CGROUP - 1);
+                    gb = (gbase + (e.y >> 16)) * MIRT_CGROUP + (2 * MIRT_CGROUP - 1);
                 }
                 if (__ballot(m != 0) == 0ull) break;
                 MIRT_DIAG(sc, DG_NARROW_ROUND, m != 0);
                 if (m != 0) {
                     const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
                     m &= m - 1u;
-                    const uint32_t idx = gi - bit + (bit >= 16u ? 32u : 0u);
+                    const uint32_t idx = (bit >= 16u ? gb : ga) - bit;
                     if constexpr (LDS::GEOM_LDS) {
                         if (RES) narrow_test(sc, GeomLdsT<LDS>{L}, idx, ray, a_true, tmin, best);
                         else narrow_test(sc, GeomGlobal<R>{sc}, idx, ray, a_true, tmin, best);
@@ -1010,6 +1039,7 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
             pt.stamp(PH_NARROW);
         }
     }
+    /* a wave whose rays can touch no tile at all (packed: need == 0) never enters the loop: best stays "no hit" */
 }
 
 /* ---- f32, scenes that do not fit the LDS: the sphere operands through a block-wide LDS ring ----------------
