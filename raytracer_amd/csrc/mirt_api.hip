@@ -368,7 +368,9 @@ static int mx_ensure(const mirt_scene* s, const mirt_scene::MxSet& set, int e) {
     const double sc = std::ldexp(1.0, e);
     const double eps = 1.0 / 16777216.0, F = 1.0 / 2097152.0; /* 2^-24, 2^-21 */
     const size_t ntiles = (balls.size() + 31) / 32;
-    std::vector<uint4> SM((ntiles + MIRT_RING_TILES + 1) * 128); /* + one tile: the streaming loop prefetches one ahead; + a chunk: trace_mx_ring stages whole chunks */
+    /* top tiles (tile cull): one for a resident scene, one per 32 tiles for scenes of up to MIRT_MX_CULL_TILES tiles beyond the LDS */
+    const size_t ntop = ntiles <= 32 ? 1 : ntiles <= MIRT_MX_CULL_TILES ? (ntiles + 31) / 32 : 0;
+    std::vector<uint4> SM((ntiles + ntop + MIRT_RING_TILES + 1) * 128); /* + one tile: the streaming loop prefetches one ahead; + a chunk: trace_mx_ring stages whole chunks */
     auto split = [](double x, _Float16& h, _Float16& l) {
         h = (_Float16)x;
         l = (_Float16)(x - (double)h);
@@ -379,8 +381,8 @@ static int mx_ensure(const mirt_scene* s, const mirt_scene::MxSet& set, int e) {
      * row no ray of the wave passes can be skipped whole (trace_mx).  A tile ball that leaves the operand range (|C| + R > 64
      * in scaled units) is marked "always" (w = -60000: q > 0 for every ray), an empty tile "never" (the dummy record). */
     std::vector<MxBall> top;
-    if (ntiles <= 32) {
-        top.assign(32, MxBall{{0, 0, 0}, 0, false});
+    if (ntop) {
+        top.assign(32 * ntop, MxBall{{0, 0, 0}, 0, false});
         const size_t per = ntiles <= 16 ? 16 : 32; /* slots per row of the top tile: scenes of <= 16 tiles get a ball per HALF tile */
         for (size_t T = 0; T < (balls.size() + per - 1) / per; ++T) {
             double lo3[3] = {1e300, 1e300, 1e300}, hi3[3] = {-1e300, -1e300, -1e300};
@@ -401,12 +403,12 @@ static int mx_ensure(const mirt_scene* s, const mirt_scene::MxSet& set, int e) {
             top[T] = t;
         }
     }
-    for (size_t T = 0; T < ntiles + (top.empty() ? 0 : 1); ++T)
+    for (size_t T = 0; T < ntiles + ntop; ++T)
         for (uint32_t row = 0; row < 32; ++row) {
-            const bool is_top = T == ntiles;
+            const bool is_top = T >= ntiles;
             const std::vector<MxBall>& src = is_top ? top : balls;
             const uint32_t sub = (row / 4) % 2, r = (row % 4) + 4 * (row / 8);
-            const size_t idx = (is_top ? 0 : 32 * T) + 16 * sub + r;
+            const size_t idx = 32 * (is_top ? T - ntiles : T) + 16 * sub + r;
             _Float16 sv[32];
             for (int k = 0; k < 32; ++k) sv[k] = (_Float16)0.f;
             sv[27] = sv[28] = sv[29] = (_Float16)1.0f;
@@ -579,11 +581,16 @@ static int occupancy_of(const void* fn, int block) {
     return per_cu;
 }
 
+#ifndef MIRT_RING_CULL
+#define MIRT_RING_CULL 0 /* A/B builds: 1 = f32 scenes beyond the LDS stay on the block-wide ring when the tile cull is on (56.3 ms on the 10 000-sphere frame against 36.6 ms: the waves of a block wait for each other at every chunk while each needs other tiles) */
+#endif
 /* Tile cull of the matrix-pipe kernels (trace_mx): 0 = every tile is evaluated (MIRT_FLAG_ALL_PAIRS; scenes beyond the LDS, whose
  * top tile does not exist; scenes of one or two tiles, where the extra tile costs more than it can save), 2 = the top tile holds
- * a ball per HALF tile (scenes of <= 16 tiles), 1 = a ball per tile - exactly as mx_ensure lays the top tile out */
+ * a ball per HALF tile (scenes of <= 16 tiles), 1 = a ball per tile, 3 = scenes beyond the LDS of up to MIRT_MX_CULL_TILES tiles:
+ * one top tile per 32 tiles (trace_mx_ring) - exactly as mx_ensure lays the top tiles out */
 static uint32_t mx_cull_mode(const mirt_scene* s, bool mx, const mirt_opts* o) {
-    if (!mx || (o->flags & MIRT_FLAG_ALL_PAIRS) || s->n > MIRT_LDS_RECORDS || s->n <= 64u) return 0u;
+    if (!mx || (o->flags & MIRT_FLAG_ALL_PAIRS) || s->n <= 64u) return 0u;
+    if (s->n > MIRT_LDS_RECORDS) return s->n <= 32u * MIRT_MX_CULL_TILES ? 3u : 0u; /* one top tile per 32 tiles; every wave streams its own tiles (trace_mx, not resident) */
     return s->n <= 512u ? 2u : 1u;
 }
 /* the two render kernels behind one name */
@@ -613,7 +620,7 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
      * LDS; 3 = brute force, broad phase on the matrix pipe; 4 = f32, a handful of spheres (render_kernel_f32_tiny);
      * 5 = 3 with the LDS layout for scenes of up to MIRT_MX_SMALL_RECORDS sorted slots (f32); 6 = 3 for scenes beyond the LDS,
      * operands through the block-wide ring (f32) */
-    const int bvh = mx ? (sizeof(R) == 4 ? (s->n <= MIRT_MX_SMALL_RECORDS ? 5 : s->n > MIRT_LDS_RECORDS ? 6 : 3) : 3) : !use_bvh ? ((sizeof(R) == 4 && s->n_live <= MIRT_TINY_SCENE) ? 4 : 0) /* 4 = the f32 kernel for a handful of spheres */
+    const int bvh = mx ? (sizeof(R) == 4 ? (s->n <= MIRT_MX_SMALL_RECORDS ? 5 : s->n > MIRT_LDS_RECORDS ? (s->mx_cull == 3u && !MIRT_RING_CULL ? 3 : 6) : 3) : 3) : !use_bvh ? ((sizeof(R) == 4 && s->n_live <= MIRT_TINY_SCENE) ? 4 : 0) /* 4 = the f32 kernel for a handful of spheres */
                     : (s->bvh_n_nodes <= MIRT_BVH_LDS_NODES && s->bvh_n_recs <= MIRT_LDS_RECORDS && s->n <= MIRT_LDS_RECORDS &&
                        s->bvh_depth <= MIRT_BVH_LDS_STACK && s->n_materials <= 0x10000u && s->bvh_root != MIRT_BVH_NONE) ? 2 : 1;
     const uint32_t block = (sizeof(R) == 4 && bvh != 1) ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;

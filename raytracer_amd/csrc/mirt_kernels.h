@@ -836,11 +836,6 @@ __device__ inline void narrow_drain(const DevScene<float>& sc, LDS& L, uint32_t 
     }
 }
 
-/* R = double (the parity-mode kernels): the same filter on the ray rounded to f32 - Dn is normalised in double first, so
- * direction and origin are each off by <= 2^-24 relatively, the f32 line passes within 5 eps (|M| + |O|) of the f64 one,
- * and 6 eps ((|M|+|O|)^2 + rho^2) replaces the 32 eps of the f32 derivation (an f64 discriminant needs ~1e-15) inside the
- * same 128 eps budget; the balls behind the operands are built around the f64 spheres (mirt_scene_create).  The narrow
- * phase is the exact f64 test. */
 /* one tile: q for 32 rays x 32 spheres per chain of two MFMAs - all that is left to the vector ALU is collecting the signs.
  * mx / my come in holding the 16-bit group numbers and leave as (group << 16) | signs: after the swap mx belongs to this lane's
  * ray and the 16 spheres of the rows of sub 0, my to the rows of sub 1 (bit 15 - k set = sphere k of the group ruled out). */
@@ -860,6 +855,47 @@ __device__ inline void mx_tile(const mirt_h8& a0, const mirt_h8& a1, const mirt_
     mx = sw[0];
     my = sw[1];
 }
+/* one top tile -> the wave's need word: bit k set = some ray of the wave may touch the ball of row k (wave-uniform) */
+__device__ inline uint32_t mx_need_word(const mirt_h8& a0, const mirt_h8& a1, const mirt_h8& bx0, const mirt_h8& bx1, const mirt_h8& by0, const mirt_h8& by1) {
+    uint32_t mx = 0, my = 0;
+    mx_tile(a0, a1, bx0, bx1, by0, by1, mx, my);
+    /* mx: this lane's ray against rows 0..15 of the top tile (bit 15 - k set = row k ruled out), my: rows 16..31;
+     * reversed and complemented: bit k set = the ray may touch the ball of row k */
+    uint32_t mine = __builtin_bitreverse32((~mx << 16) | (~my & 0xFFFFu));
+    mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x111, 0xF, 0xF, false); /* OR over the wave, as wave_scan_incl adds */
+    mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x112, 0xF, 0xF, false);
+    mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x114, 0xF, 0xF, false);
+    mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x118, 0xF, 0xF, false);
+    mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x142, 0xA, 0xF, false);
+    mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x143, 0xC, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)mine, 63);
+}
+#ifdef MIRT_VERIFY_BROAD
+/* diagnostic build: the 16 spheres of group g against this lane's ray, exactly - a sphere whose discriminant is >= 0 must have
+ * its bit clear in `word` (word = all ones for a group the cull skipped) */
+template <class R>
+__device__ inline void mx_verify_group(const DevScene<R>& sc, const RayT<R>& ray, RayA<R> a_true, bool active, uint32_t g, uint32_t word) {
+    for (uint32_t k_ = 0; k_ < 16; ++k_) {
+        const uint32_t i_ = g * 16 + k_;
+        if (i_ >= sc.n) break;
+        typename Vec4<R>::type sa_ = sc.A[i_];
+        V3<R> C_ = {sa_.x, sa_.y, sa_.z};
+        if (i_ >= sc.n_static) {
+            typename Vec4<R>::type sb_ = sc.B[i_];
+            C_ = center_at(C_, V3<R>{sb_.x, sb_.y, sb_.z}, ray.tm);
+        }
+        R hh_, dd_;
+        disc(C_ - ray.o, ray.d, a_true, sa_.w, hh_, dd_);
+        if (active && dd_ >= (R)0.0 && ((word >> (15 - k_)) & 1u)) atomicAdd(sc.dbg, 1ull);
+    }
+}
+#endif
+
+/* R = double (the parity-mode kernels): the same filter on the ray rounded to f32 - Dn is normalised in double first, so
+ * direction and origin are each off by <= 2^-24 relatively, the f32 line passes within 5 eps (|M| + |O|) of the f64 one,
+ * and 6 eps ((|M|+|O|)^2 + rho^2) replaces the 32 eps of the f32 derivation (an f64 discriminant needs ~1e-15) inside the
+ * same 128 eps budget; the balls behind the operands are built around the f64 spheres (mirt_scene_create).  The narrow
+ * phase is the exact f64 test. */
 template <class R, class LDS, bool RES>
 __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint32_t lane, bool active, const RayT<R>& ray, R tmin,
                                 Closest<R>& best, uint32_t& narrow_count, PhaseTimer& pt, uint32_t& tiles_done) {
@@ -889,40 +925,48 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
      * spheres in a spatial order most tiles drop out. */
     uint32_t need = 0xFFFFFFFFu;
     if (RES && sc.mx_cull) {
-        uint32_t mx = 0, my = 0;
-        mx_tile(SM[ntiles * 128 + lane], SM[ntiles * 128 + 64 + lane], bx0, bx1, by0, by1, mx, my);
-        /* mx: this lane's ray against rows 0..15 of the top tile (bit 15 - k set = row k ruled out), my: rows 16..31;
-         * reversed and complemented: bit k set = the ray may touch the ball of row k */
-        uint32_t mine = __builtin_bitreverse32((~mx << 16) | (~my & 0xFFFFu));
-        mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x111, 0xF, 0xF, false); /* OR over the wave, as wave_scan_incl adds */
-        mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x112, 0xF, 0xF, false);
-        mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x114, 0xF, 0xF, false);
-        mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x118, 0xF, 0xF, false);
-        mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x142, 0xA, 0xF, false);
-        mine |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x143, 0xC, 0xF, false);
-        need = (uint32_t)__builtin_amdgcn_readlane((int)mine, 63);
+        need = mx_need_word(SM[ntiles * 128 + lane], SM[ntiles * 128 + 64 + lane], bx0, bx1, by0, by1);
         ++tiles_done; /* the top tile is a tile's worth of work too */
     }
     pt.stamp(PH_OTHER); /* phase-timing build: "other" = the ray operands and the top tile */
 #ifdef MIRT_VERIFY_BROAD
-    /* the 16 spheres of group g against this lane's ray, exactly: a sphere whose discriminant is >= 0 must have its bit clear
-     * in `word` (word = all ones for a group the cull skipped) */
-    auto verify_group = [&](uint32_t g, uint32_t word) {
-        for (uint32_t k_ = 0; k_ < 16; ++k_) {
-            const uint32_t i_ = g * 16 + k_;
-            if (i_ >= sc.n) break;
-            typename Vec4<R>::type sa_ = sc.A[i_];
-            V3<R> C_ = {sa_.x, sa_.y, sa_.z};
-            if (i_ >= sc.n_static) {
-                typename Vec4<R>::type sb_ = sc.B[i_];
-                C_ = center_at(C_, V3<R>{sb_.x, sb_.y, sb_.z}, ray.tm);
-            }
-            R hh_, dd_;
-            disc(C_ - ray.o, ray.d, a_true, sa_.w, hh_, dd_);
-            if (active && dd_ >= (R)0.0 && ((word >> (15 - k_)) & 1u)) atomicAdd(sc.dbg, 1ull);
-        }
-    };
+    auto verify_group = [&](uint32_t g, uint32_t word) { mx_verify_group(sc, ray, a_true, active, g, word); };
 #endif
+    /* scenes that are not resident (streamed from L1/L2 per wave: K1 and the f64 kernels beyond their LDS layouts): one top tile per
+     * 32 tiles behind the last tile (mx_cull 1: one, 3: several), one need word per top tile in lane j of `needv`, and the loop
+     * below walks - and prefetches - only the tiles of this wave */
+    const bool streamed = !RES && (sc.mx_cull == 1u || sc.mx_cull == 3u);
+    uint32_t needv = 0xFFFFFFFFu;
+    auto next_needed = [&](uint32_t from) -> uint32_t { /* the first tile >= from of this wave's, ntiles if there is none (wave-uniform) */
+        uint32_t u = from;
+        while (u < ntiles) {
+            const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)needv, (int)(u >> 5)) >> (u & 31u);
+            if (word) { u += (uint32_t)__builtin_ctz(word); break; }
+            u = (u | 31u) + 1u;
+        }
+        return u < ntiles ? u : ntiles;
+    };
+    if (streamed) {
+        const uint32_t ntop = (ntiles + 31u) / 32u; /* <= 32 (mx_cull_mode) */
+        mirt_h8 p0 = SM[ntiles * 128 + lane], p1 = SM[ntiles * 128 + 64 + lane];
+        for (uint32_t j = 0; j < ntop; ++j) {
+            const mirt_h8 a0 = p0, a1 = p1;
+            if (j + 1u < ntop) { p0 = SM[(ntiles + j + 1u) * 128 + lane]; p1 = SM[(ntiles + j + 1u) * 128 + 64 + lane]; }
+            const uint32_t wj = mx_need_word(a0, a1, bx0, bx1, by0, by1);
+            needv = lane == j ? wj : needv;
+            ++tiles_done;
+        }
+#ifdef MIRT_VERIFY_BROAD
+        for (uint32_t s_ = 0; s_ < ntiles; ++s_)
+            if (!(((uint32_t)__builtin_amdgcn_readlane((int)needv, (int)(s_ >> 5)) >> (s_ & 31u)) & 1u)) {
+                verify_group(2 * s_, 0xFFFFu);
+                verify_group(2 * s_ + 1, 0xFFFFu);
+            }
+#endif
+        t = next_needed(0u);
+        if (t < ntiles) { pre0 = SM[t * 128 + lane]; pre1 = SM[t * 128 + 64 + lane]; }
+        pt.stamp(PH_OTHER);
+    }
     /* mx_cull 2 (scenes of <= 16 tiles): row h of the top tile is the ball of HALF tile h (16 spheres), and the loop runs over
      * the half tiles the wave needs, two at a time: the rows of sub 0 of the A operand are fetched from the first, those of sub 1
      * from the second - a per-lane LDS address, nothing else - so a tile of which only one half is needed costs half a tile. */
@@ -960,6 +1004,23 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
                 for (uint32_t g_ = 0; g_ < 2 * ntiles; ++g_)
                     if (!((need >> g_) & 1u)) verify_group(g_, 0xFFFFu);
 #endif
+        } else if (streamed) { /* <= 1024 tiles: the 16-bit group numbers cannot run out within a pass */
+            while (t < ntiles && !flush) {
+                const mirt_h8 a0 = pre0, a1 = pre1;
+                const uint32_t tn = next_needed(t + 1u);
+                if (tn < ntiles) { pre0 = SM[tn * 128 + lane]; pre1 = SM[tn * 128 + 64 + lane]; }
+                uint32_t mx = 2 * t - gbase + sub, my = mx;
+                mx_tile(a0, a1, bx0, bx1, by0, by1, mx, my);
+#ifdef MIRT_VERIFY_BROAD
+                verify_group(2 * t, mx);
+                verify_group(2 * t + 1, my);
+#endif
+                ent2[cnt][lane] = make_uint2(mx, my);
+                cnt += ((mx & my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
+                flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull;
+                ++tiles_done;
+                t = tn;
+            }
         } else {
         uint32_t tlimit = t + 0x8000u; /* group numbers in the entries are 16 bit, relative to gbase */
         tlimit = tlimit < ntiles ? tlimit : ntiles;
@@ -1051,12 +1112,13 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
  * The price is that the waves are no longer free-running: every wave of the block must make every call with the same
  * number of barriers (MIRT_RING chunks + 1, a function of the scene alone), so render_body keeps idle waves in the loop
  * until the whole block is out of work (T::LOCKSTEP), and a wave without a ray still stages and waits. */
+#define MIRT_MX_CULL_TILES 1024u /* scenes beyond the LDS: the tile cull keeps one need word per 32 tiles in the lanes of a VGPR (<= 32 top tiles = 32 768 spheres) */
 #ifndef MIRT_RING_TILES
 #define MIRT_RING_TILES 24u /* two chunks of 24 tiles = 96 KB: the operand area and the (unused, the scene is not resident) A / B areas behind it; 8 / 16 / 24 tiles: 119.5 / 116.0 / 114.0 ms on the 10 000-sphere frame */
 #endif
 template <class LDS>
 __device__ inline void trace_mx_ring(const DevScene<float>& sc, LDS& L, uint32_t w, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
-                                     Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
+                                     Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt, uint32_t& tiles_done) {
     static_assert(offsetof(LDS, A) == sizeof(L.SM) && offsetof(LDS, B) == offsetof(LDS, A) + sizeof(L.A), "SM, A, B must be contiguous: the ring runs over all three");
     static_assert((sizeof(L.SM) + sizeof(L.A) + sizeof(L.B)) / 16u >= 2u * MIRT_RING_TILES * 128u, "the ring must hold two chunks");
     static_assert((MIRT_RING_TILES * 2u) % MIRT_F32_WAVES == 0u, "whole slabs per wave");
@@ -1097,6 +1159,25 @@ __device__ inline void trace_mx_ring(const DevScene<float>& sc, LDS& L, uint32_t
     };
     const uint32_t sub = lane >> 5;
     stage(0);
+    /* ---- tile cull (mx_cull 3): the top tiles behind the last tile hold a ball around each tile (row k of top tile j: tile
+     * 32 j + k), as for resident scenes (trace_mx); each wave fetches them from L1/L2 for itself - 2 KB per 32 tiles - while
+     * chunk 0 is on its way, and keeps the tiles its rays may touch as one 32-bit word per top tile in lane j of `needv`.  The
+     * chunks are staged for the whole block as before; a wave runs only its own tiles of each through the matrix pipe. */
+    const bool cull = sc.mx_cull == 3u;
+    uint32_t needv = 0xFFFFFFFFu;
+    if (cull && wave_live) {
+        const uint32_t ntop = (ntiles + 31u) / 32u; /* <= 32 (mx_cull_mode) */
+        const mirt_h8* G = (const mirt_h8*)sc.SM + (size_t)ntiles * 128u;
+        mirt_h8 p0 = G[lane], p1 = G[64u + lane];
+        for (uint32_t j = 0; j < ntop; ++j) {
+            const mirt_h8 a0 = p0, a1 = p1;
+            if (j + 1u < ntop) { p0 = G[(j + 1u) * 128u + lane]; p1 = G[(j + 1u) * 128u + 64u + lane]; }
+            const uint32_t wj = mx_need_word(a0, a1, bx0, bx1, by0, by1);
+            needv = lane == j ? wj : needv;
+            ++tiles_done;
+        }
+        pt.stamp(PH_OTHER);
+    }
     __syncthreads(); /* waits for the copies (vmcnt) and for the other waves: also fences the previous call's readers */
     uint32_t t = 0, cnt = 0, gbase = 0;
     for (uint32_t c = 0; c < nch; ++c) {
@@ -1108,25 +1189,33 @@ __device__ inline void trace_mx_ring(const DevScene<float>& sc, LDS& L, uint32_t
             t_end = t_end < ntiles ? t_end : ntiles;
             while (t < t_end) {
                 bool flush = false;
-                for (; t < t_end && !flush; ++t) {
+                while (t < t_end && !flush) {
+                    if (cull) { /* on to the next tile of this wave's (wave-uniform: scalar code) */
+                        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)needv, (int)(t >> 5)) >> (t & 31u);
+                        const uint32_t t_next = word ? t + (uint32_t)__builtin_ctz(word) : (t | 31u) + 1u;
+#ifdef MIRT_VERIFY_BROAD
+                        for (uint32_t s_ = t; s_ < t_next && s_ < t_end; ++s_) { /* no sphere of a skipped tile may have an exact discriminant >= 0 */
+                            mx_verify_group(sc, ray, a_true, active, 2 * s_, 0xFFFFu);
+                            mx_verify_group(sc, ray, a_true, active, 2 * s_ + 1, 0xFFFFu);
+                        }
+#endif
+                        t = t_next;
+                        if (t >= t_end) break;
+                    }
                     const mirt_h8 a0 = buf[(t - t0) * 128u + lane], a1 = buf[(t - t0) * 128u + 64u + lane];
-                    const mirt_f16v zero = {};
                     uint32_t mx = 2 * t - gbase + sub, my = mx;
-                    mirt_f16v qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bx0, zero, 0, 0, 0);
-                    mirt_f16v qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, by0, zero, 0, 0, 0);
-                    qx = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bx1, qx, 0, 0, 0);
-                    qy = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, by1, qy, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = __builtin_amdgcn_alignbit(mx, __float_as_uint(qx[r]), 31);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) my = __builtin_amdgcn_alignbit(my, __float_as_uint(qy[r]), 31);
-                    auto sw = __builtin_amdgcn_permlane32_swap(mx, my, false, false);
-                    mx = sw[0];
-                    my = sw[1];
+                    mx_tile(a0, a1, bx0, bx1, by0, by1, mx, my);
+#ifdef MIRT_VERIFY_BROAD
+                    mx_verify_group(sc, ray, a_true, active, 2 * t, mx);
+                    mx_verify_group(sc, ray, a_true, active, 2 * t + 1, my);
+#endif
                     ent2[cnt][lane] = make_uint2(mx, my);
                     cnt += ((mx & my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
                     flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull;
+                    ++tiles_done;
+                    ++t;
                 }
+                t = t < t_end ? t : t_end; /* the skip may have looked past the chunk: the next chunk starts at its first tile */
                 /* a full list, or 0x7FFF tiles behind the pass's first one (group numbers in the entries are 16 bit) */
                 if (flush || 2u * t - gbase >= 0xFFFEu) {
                     pt.stamp(PH_BROAD);
@@ -1489,8 +1578,7 @@ template <class LDS> struct TracerF32MxRing {
     uint32_t w;
     uint32_t tiles = 0;
     __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
-        if (__ballot(active) != 0ull) tiles += (sc.n + 31u) / 32u;
-        trace_mx_ring<LDS>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
+        trace_mx_ring<LDS>(sc, L, w, lane, active, ray, tmin, best, nc, pt, tiles);
     }
     __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const { return make_hit(sc, GeomGlobal<float>{sc}, c, ray); }
     __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }

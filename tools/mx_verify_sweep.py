@@ -16,7 +16,7 @@ mats = [Lambertian.new((0.6, 0.6, 0.6), 1.0), Metal.new((0.9, 0.9, 0.9), None), 
 n_matrix = 0
 for case in range(40):
     scale = float(2.0 ** rng.integers(-12, 13))
-    n = int(rng.integers(24, 700))
+    n = int(rng.integers(int(os.environ.get("MIRT_SWEEP_NMIN", "24")), int(os.environ.get("MIRT_SWEEP_NMAX", "700"))))  # beyond 1024: the ring kernel and its top tiles
     ext = float(rng.uniform(2.0, 60.0))
     big = rng.random() < 0.6
     sc = Scene()
