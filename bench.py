@@ -41,6 +41,11 @@ MX_CYCLES_PER_WAVE_SEGMENT = 3 * 2
 # instructions issue for free in the 32-cycle shadow of each MFMA, so of the 32 per tile only 32 - 4 x 4.5 = 14 cost their
 # 2 cycles.  The lower (harder) of the two bounds; both are printed.
 MX_CYCLES_PER_WAVE_TILE_SHADOW = 4 * 32 + (32 - 4 * 4.5) * 2
+# What the tile loop ALONE does on this chip, whatever the order of its instructions (bench/mx_tile_rate.hip, five schedules,
+# 4 waves per SIMD, profiles/r03_mx_tile_rate.txt): 185-194 shader cycles per wave-tile.  v_alignbit_b32 (one per ray-sphere
+# pair) issues at 3.4 cycles, not 2 (bench/valu_op_rate.hip); the 32 of a tile and the ~15 other VALU instructions fill the time
+# the four MFMAs leave.  Not a bound - a measured ceiling of this formulation, printed beside the two bounds.
+MX_CYCLES_PER_WAVE_TILE_MEASURED = 190
 PROFILE_TAGS = {("balls1080p", 1): "r03_mx", ("balls1080p", 0): "r03_valu", ("stress10000", 1): "r03_stress10k", ("stress10000", 0): "r03_stress10k_valu",
                 ("textured", 5): "r03_textured"}
 PROFILE_FALLBACK = {"r03_": "r02_"}  # a workload not re-profiled this round falls back to the last round's committed passes
@@ -82,6 +87,23 @@ def profile_traffic(tag, kernel):
     if len(vals) != 2:
         return None
     return {"bytes": vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "fetch": vals["FETCH_SIZE"], "write": vals["WRITE_SIZE"], "file": f"profiles/{tag}_hbm_traffic.txt"}
+
+
+def profile_phase_split(tag):
+    """Shares of the render kernel's wave-cycles per phase from the committed pass profiles/<tag>_phase_split.txt (the
+    -DMIRT_PHASE_TIMING build, tools/phase_split.sh): {'queue': .., 'raygen': .., 'broad': .., 'narrow': .., 'shade': .., 'other': ..}."""
+    path = os.path.join(ROOT, "profiles", f"{tag}_phase_split.txt")
+    if not os.path.exists(path):
+        return None
+    import re
+
+    for line in open(path):
+        if "wave-cycles:" in line:
+            d = {k: float(v) / 100.0 for k, v in re.findall(r"(queue|raygen|broad|narrow|shade|other) ([0-9.]+)%", line)}
+            if d:
+                d["file"] = f"profiles/{tag}_phase_split.txt"
+                return d
+    return None
 
 
 def profile_valu_rate(tag):
@@ -495,8 +517,23 @@ def main():
                                                 "note": "the same mandatory slots with the ~4.5 VALU instructions per MFMA that issue for free in its shadow taken off "
                                                         "(bench/mfma_coexec.hip): the harder bound; `frac` above prices MFMA and VALU additively"},
                          "vs_fp32_valu_peak": round(achieved / FP32_VALU_PEAK_TFLOPS, 4)})
+            t_loop = (seg / 64.0) * (tiles * MX_CYCLES_PER_WAVE_TILE_MEASURED) / (cus * SIMDS_PER_CU * NOMINAL_CLOCK_GHZ * 1e9)
+            roof["tile_loop_measured"] = {"cycles_per_wave_tile": MX_CYCLES_PER_WAVE_TILE_MEASURED, "ms_per_launch": round(t_loop / n_launch * 1e3, 3),
+                                          "source": "profiles/r03_mx_tile_rate.txt (bench/mx_tile_rate.hip: the tile loop alone, five instruction orders, 4 waves per SIMD)",
+                                          "note": "what the evaluated tiles cost at the rate the tile loop reaches in isolation, at the nominal clock"}
+            ph = profile_phase_split(tag) if tag else None
+            if ph and depth == 1:
+                broad_ms = (ph.get("broad", 0.0) + ph.get("other", 0.0)) * ms_avg
+                roof["broad_phase"] = {"share_of_kernel": round(ph.get("broad", 0.0) + ph.get("other", 0.0), 4), "ms": round(broad_ms, 3),
+                                       "frac_of_bound": round(t_bound / n_launch * 1e3 / broad_ms, 4) if broad_ms > 0 else None,
+                                       "frac_of_measured_tile_loop": round(t_loop / n_launch * 1e3 / broad_ms, 4) if broad_ms > 0 else None,
+                                       "other_phases": {k: ph[k] for k in ("narrow", "shade", "raygen", "queue") if k in ph},
+                                       "source": ph["file"],
+                                       "note": "the bound prices the broad phase only; this is the share of the kernel's wave-cycles the broad phase takes (tile loop + ray "
+                                               "operands + top tile, -DMIRT_PHASE_TIMING build) and the bound against THAT time; the rest of the kernel is the exact narrow "
+                                               "phase, shading, ray generation and the work queue, which no flop count prices"}
             note += (f"; bound = mandatory issue slots of the matrix-pipe broad phase: per wave and segment {tiles:.2f} tiles evaluated (of {tiles_all}: the tile cull skips the tiles no ray of a wave "
-                     f"can touch; the count includes the top tile it tests first) x (4 MFMA x 32 + 32 VALU x 2 cycles) + 6 = {cyc:.0f} SIMD-cycles, "
+                     f"can touch; the count includes the top tile(s) it tests first) x (4 MFMA x 32 + 32 VALU x 2 cycles) + 6 = {cyc:.0f} SIMD-cycles, "
                      f"segments / 64 waves, {cus * SIMDS_PER_CU} SIMDs at the nominal {NOMINAL_CLOCK_GHZ} GHz; `peak` is that bound expressed in the same algorithmic flops, so frac = bound time / kernel time; "
                      "`vs_fp32_valu_peak` is the algorithmic rate against the vector-ALU peak alone, which this kernel can exceed because 8 of the 9 VALU operations per pair moved to the "
                      "matrix pipe - the metric's '% of FP32 VALU peak' is `valu_broad.frac` (render_kernel_f32, every pair on the vector ALU)")
