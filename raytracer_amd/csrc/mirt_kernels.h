@@ -971,7 +971,9 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
      * the half tiles the wave needs, two at a time: the rows of sub 0 of the A operand are fetched from the first, those of sub 1
      * from the second - a per-lane LDS address, nothing else - so a tile of which only one half is needed costs half a tile. */
     const bool packed = RES && sc.mx_cull == 2u;
-    uint32_t rem = packed ? need : 0u;
+    /* only rows that stand for a half tile: a lane marked "every record is a candidate" (origin out of range, NaN: c0 = +60 000)
+     * also passes the "never" rows behind them (q = +0), and those have no spheres, not even dummy records, to meet */
+    uint32_t rem = packed ? need & (0xFFFFFFFFu >> (32u - 2u * ntiles)) : 0u;
     while (packed ? rem != 0u : t < ntiles) { /* one pass unless some lane's entry list fills up */
         prio_broad();
         uint32_t cnt = 0;

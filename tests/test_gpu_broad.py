@@ -407,3 +407,38 @@ def test_tile_cull_changes_nothing_but_the_work(oracle, prec):
         if prec == abi.F32:
             o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F32, seed=3, threads=8, spec_chunk=cam.pass_granularity(precision=abi.F32))
             assert o_seg == a[5] and np.array_equal(a[0].view(np.uint32), o_lin.view(np.uint32)), name
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F64])
+def test_tile_cull_lanes_that_keep_every_record(oracle, prec):
+    """A ray the matrix-pipe filter cannot judge (NaN; an origin outside the operand range) is marked "every record is a
+    candidate" by its own operands.  Such a lane passes every row of a top tile - also the empty rows behind the last half tile,
+    which stand for no spheres at all - so the loop over the needed half tiles must stop at the last real one.  A camera whose
+    pixel grid has a NaN component makes every ray such a lane: the culled loop, MIRT_FLAG_ALL_PAIRS, the vector-ALU kernel
+    and the oracle must agree on every hit and on the frame (bench scene and a scene of 10 tiles: the packed loop over half
+    tiles; 2 500 spheres: beyond the LDS).  What the exact test makes of a NaN ray is the specification's business (its max / min drop NaNs); this test only
+    holds the front ends to each other and to the oracle."""
+    lib = abi.load()
+    two_clusters = _cull_scenes()[1]  # 10 tiles: rows 20..31 of its top tile are empty
+    for sc, cam in ((presets.bouncing_balls_scene(1), presets.bouncing_balls_camera(96, 2, 8)), two_clusters[1:], (presets.stress_scene(2500, 3), presets.stress_camera(96, 2, 8))):
+        ds = sc.device_scene(0)
+        bad = Camera(cam.pod)
+        bad.pod.px00_loc[1] = float("nan")
+        assert bad.closest_hit_kind(sc, precision=prec) in ("matrix", "f64-matrix")
+        H, W = bad.height, bad.width
+        o_ids, o_t = oracle.primary_hits(sc.flat, bad.pod, prec)
+        res = {}
+        for flags in (0, abi.FLAG_ALL_PAIRS, abi.FLAG_VALU_BROAD):
+            o = bad.opts(precision=prec, seed=4, flags=flags)
+            ids = np.full((H, W), 7, np.uint32)
+            t = np.empty((H, W), np.float64 if prec == abi.F64 else np.float32)
+            abi.check(lib.mirt_primary_hits(ds.handle, C.byref(bad.pod), C.byref(o), ids.ctypes.data, t.ctypes.data))
+            lin = np.empty((H, W, 3), t.dtype)
+            st = abi.MirtStats()
+            abi.check(lib.mirt_render(ds.handle, C.byref(bad.pod), C.byref(o), lin.ctypes.data, None, C.byref(st)))
+            res[flags] = (ids, t, lin, st.segments)
+            assert np.array_equal(ids, o_ids), flags
+            assert np.array_equal(t[ids != 0xFFFFFFFF], o_t[ids != 0xFFFFFFFF]), flags
+        for flags in (abi.FLAG_ALL_PAIRS, abi.FLAG_VALU_BROAD):
+            assert res[0][3] == res[flags][3]
+            assert np.array_equal(res[0][2].view(np.uint8), res[flags][2].view(np.uint8)), flags
