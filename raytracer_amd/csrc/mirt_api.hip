@@ -581,32 +581,31 @@ static int occupancy_of(const void* fn, int block) {
     return per_cu;
 }
 
-#ifndef MIRT_RING_CULL
-#define MIRT_RING_CULL 0 /* A/B builds: 1 = f32 scenes beyond the LDS stay on the block-wide ring when the tile cull is on (56.3 ms on the 10 000-sphere frame against 36.6 ms: the waves of a block wait for each other at every chunk while each needs other tiles) */
-#endif
 /* Tile cull of the matrix-pipe kernels (trace_mx): 0 = every tile is evaluated (MIRT_FLAG_ALL_PAIRS; scenes beyond the LDS, whose
  * top tile does not exist; scenes of one or two tiles, where the extra tile costs more than it can save), 2 = the top tile holds
  * a ball per HALF tile (scenes of <= 16 tiles), 1 = a ball per tile, 3 = scenes beyond the LDS of up to MIRT_MX_CULL_TILES tiles:
  * one top tile per 32 tiles (trace_mx_ring) - exactly as mx_ensure lays the top tiles out */
 static uint32_t mx_cull_mode(const mirt_scene* s, bool mx, const mirt_opts* o) {
     if (!mx || (o->flags & MIRT_FLAG_ALL_PAIRS) || s->n <= 64u) return 0u;
-    if (s->n > MIRT_LDS_RECORDS) return s->n <= 32u * MIRT_MX_CULL_TILES ? 3u : 0u; /* one top tile per 32 tiles; every wave streams its own tiles (trace_mx, not resident) */
+    if (s->n > MIRT_LDS_RECORDS) return s->n <= 32u * MIRT_MX_CULL_TILES ? 3u : 0u; /* one top tile per 32 tiles; every wave streams its own tiles (trace_mx, not resident); beyond: every tile, through the ring */
     return s->n <= 512u ? 2u : 1u;
 }
 /* the two render kernels behind one name */
-static const void* render_fn(double, int bvh) { return bvh == 3 ? (const void*)render_kernel_f64_mx : (const void*)render_kernel_f64<2>; }
-static const void* render_fn(float, int bvh) { return bvh == 4 ? (const void*)render_kernel_f32_tiny : bvh == 6 ? (const void*)render_kernel_f32_mx_ring : bvh == 5 ? (const void*)render_kernel_f32_mx<MxLdsSmall> : bvh == 3 ? (const void*)render_kernel_f32_mx<MxLds> : bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
+static const void* render_fn(double, int bvh) { return bvh == 3 ? (const void*)render_kernel_f64_mx<true> : bvh == 7 ? (const void*)render_kernel_f64_mx<false> : (const void*)render_kernel_f64<2>; }
+static const void* render_fn(float, int bvh) { return bvh == 4 ? (const void*)render_kernel_f32_tiny : bvh == 6 ? (const void*)render_kernel_f32_mx_ring : bvh == 7 ? (const void*)render_kernel_f32_mx<MxLds, false> : bvh == 5 ? (const void*)render_kernel_f32_mx<MxLdsSmall, true> : bvh == 3 ? (const void*)render_kernel_f32_mx<MxLds, true> : bvh == 2 ? (const void*)render_kernel_f32_bvh_lds : bvh ? (const void*)render_kernel_f32_bvh : (const void*)render_kernel_f32; }
 static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<double>& sc, const DevCamera<double>& cam,
                                  const DevPart& part, const RenderParams& rp, double* partial, DevStats* stats, double* att) {
-    if (bvh == 3) hipLaunchKernelGGL(render_kernel_f64_mx, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats, att);
+    if (bvh == 3) hipLaunchKernelGGL(render_kernel_f64_mx<true>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats, att);
+    else if (bvh == 7) hipLaunchKernelGGL(render_kernel_f64_mx<false>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats, att);
     else hipLaunchKernelGGL(render_kernel_f64<2>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats, att);
 }
 static void launch_render_kernel(uint32_t grid, uint32_t block, int bvh, hipStream_t st, const DevScene<float>& sc, const DevCamera<float>& cam,
                                  const DevPart& part, const RenderParams& rp, float* partial, DevStats* stats, float*) {
     if (bvh == 4) hipLaunchKernelGGL(render_kernel_f32_tiny, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh == 6) hipLaunchKernelGGL(render_kernel_f32_mx_ring, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
-    else if (bvh == 5) hipLaunchKernelGGL(render_kernel_f32_mx<MxLdsSmall>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
-    else if (bvh == 3) hipLaunchKernelGGL(render_kernel_f32_mx<MxLds>, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    else if (bvh == 7) hipLaunchKernelGGL((render_kernel_f32_mx<MxLds, false>), dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    else if (bvh == 5) hipLaunchKernelGGL((render_kernel_f32_mx<MxLdsSmall, true>), dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
+    else if (bvh == 3) hipLaunchKernelGGL((render_kernel_f32_mx<MxLds, true>), dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh == 2) hipLaunchKernelGGL(render_kernel_f32_bvh_lds, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else if (bvh) hipLaunchKernelGGL(render_kernel_f32_bvh, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
     else hipLaunchKernelGGL(render_kernel_f32, dim3(grid), dim3(block), 0, st, sc, cam, part, rp, partial, stats);
@@ -619,8 +618,9 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     /* closest-hit front end: 0 = brute force, VALU broad phase; 1 = tree in HBM/L2; 2 = tree, records and spheres resident in
      * LDS; 3 = brute force, broad phase on the matrix pipe; 4 = f32, a handful of spheres (render_kernel_f32_tiny);
      * 5 = 3 with the LDS layout for scenes of up to MIRT_MX_SMALL_RECORDS sorted slots (f32); 6 = 3 for scenes beyond the LDS,
-     * operands through the block-wide ring (f32) */
-    const int bvh = mx ? (sizeof(R) == 4 ? (s->n <= MIRT_MX_SMALL_RECORDS ? 5 : s->n > MIRT_LDS_RECORDS ? (s->mx_cull == 3u && !MIRT_RING_CULL ? 3 : 6) : 3) : 3) : !use_bvh ? ((sizeof(R) == 4 && s->n_live <= MIRT_TINY_SCENE) ? 4 : 0) /* 4 = the f32 kernel for a handful of spheres */
+     * every tile, operands through the block-wide ring (f32); 7 = 3 for scenes beyond the LDS with the tile cull: every wave
+     * streams its own tiles (f32; the f64 kernel decides resident / streamed by itself) */
+    const int bvh = mx ? (sizeof(R) == 4 ? (s->n <= MIRT_MX_SMALL_RECORDS ? 5 : s->n > MIRT_LDS_RECORDS ? (s->mx_cull == 3u ? 7 : 6) : 3) : (s->n <= MIRT_MX64_RECORDS ? 3 : 7)) : !use_bvh ? ((sizeof(R) == 4 && s->n_live <= MIRT_TINY_SCENE) ? 4 : 0) /* 4 = the f32 kernel for a handful of spheres */
                     : (s->bvh_n_nodes <= MIRT_BVH_LDS_NODES && s->bvh_n_recs <= MIRT_LDS_RECORDS && s->n <= MIRT_LDS_RECORDS &&
                        s->bvh_depth <= MIRT_BVH_LDS_STACK && s->n_materials <= 0x10000u && s->bvh_root != MIRT_BVH_NONE) ? 2 : 1;
     const uint32_t block = (sizeof(R) == 4 && bvh != 1) ? MIRT_F32_BLOCK : MIRT_BLOCK, waves_per_block = block / MIRT_WAVE;
@@ -991,8 +991,8 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
         if ((rc = static_scratch_ptr(device, &sp))) { mirt_scene_destroy(s); return rc; }
         /* resident blocks per CU of every render kernel this scene can select: asked here, so that no render call - least of
          * all mirt_render_device_static - ever reaches hipOccupancyMaxActiveBlocksPerMultiprocessor or grows the cache */
-        for (int k = 0; k <= 6; ++k) (void)occupancy_of(render_fn(float(), k), k == 1 ? (int)MIRT_BLOCK : (int)MIRT_F32_BLOCK);
-        for (int k : {0, 3}) (void)occupancy_of(render_fn(double(), k), (int)MIRT_BLOCK);
+        for (int k = 0; k <= 7; ++k) (void)occupancy_of(render_fn(float(), k), k == 1 ? (int)MIRT_BLOCK : (int)MIRT_F32_BLOCK);
+        for (int k : {0, 3, 7}) (void)occupancy_of(render_fn(double(), k), (int)MIRT_BLOCK);
         /* operands for a camera inside or near the scene (the scale then follows from the scene's extent alone) */
         mirt_camera c0;
         memset(&c0, 0, sizeof(c0));

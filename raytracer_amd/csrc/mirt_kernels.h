@@ -932,33 +932,37 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
 #ifdef MIRT_VERIFY_BROAD
     auto verify_group = [&](uint32_t g, uint32_t word) { mx_verify_group(sc, ray, a_true, active, g, word); };
 #endif
-    /* scenes that are not resident (streamed from L1/L2 per wave: K1 and the f64 kernels beyond their LDS layouts): one top tile per
-     * 32 tiles behind the last tile (mx_cull 1: one, 3: several), one need word per top tile in lane j of `needv`, and the loop
-     * below walks - and prefetches - only the tiles of this wave */
+    /* scenes that are not resident (every wave streams its tiles from L1/L2: f32 beyond 1024 spheres, f64 beyond 512, K1): one top
+     * tile per 32 tiles behind the last tile (mx_cull 1: one, 3: several), one need word per top tile in the lanes of `needv0/1`,
+     * and the loop below walks - and prefetches - only the tiles of this wave */
     const bool streamed = !RES && (sc.mx_cull == 1u || sc.mx_cull == 3u);
-    uint32_t needv = 0xFFFFFFFFu;
+    uint32_t needv0 = 0xFFFFFFFFu, needv1 = 0xFFFFFFFFu; /* lane j of needv0: tiles 32 j .. 32 j + 31; of needv1: the same + 2048 */
+    auto need_word = [&](uint32_t j) -> uint32_t { /* wave-uniform j: a scalar lane index */
+        return (uint32_t)(j < 64u ? __builtin_amdgcn_readlane((int)needv0, (int)j) : __builtin_amdgcn_readlane((int)needv1, (int)(j - 64u)));
+    };
     auto next_needed = [&](uint32_t from) -> uint32_t { /* the first tile >= from of this wave's, ntiles if there is none (wave-uniform) */
         uint32_t u = from;
         while (u < ntiles) {
-            const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)needv, (int)(u >> 5)) >> (u & 31u);
+            const uint32_t word = need_word(u >> 5) >> (u & 31u);
             if (word) { u += (uint32_t)__builtin_ctz(word); break; }
             u = (u | 31u) + 1u;
         }
         return u < ntiles ? u : ntiles;
     };
     if (streamed) {
-        const uint32_t ntop = (ntiles + 31u) / 32u; /* <= 32 (mx_cull_mode) */
+        const uint32_t ntop = (ntiles + 31u) / 32u; /* <= 128 (mx_cull_mode: MIRT_MX_CULL_TILES) */
         mirt_h8 p0 = SM[ntiles * 128 + lane], p1 = SM[ntiles * 128 + 64 + lane];
         for (uint32_t j = 0; j < ntop; ++j) {
             const mirt_h8 a0 = p0, a1 = p1;
             if (j + 1u < ntop) { p0 = SM[(ntiles + j + 1u) * 128 + lane]; p1 = SM[(ntiles + j + 1u) * 128 + 64 + lane]; }
             const uint32_t wj = mx_need_word(a0, a1, bx0, bx1, by0, by1);
-            needv = lane == j ? wj : needv;
+            needv0 = lane == j ? wj : needv0;
+            needv1 = lane + 64u == j ? wj : needv1;
             ++tiles_done;
         }
 #ifdef MIRT_VERIFY_BROAD
         for (uint32_t s_ = 0; s_ < ntiles; ++s_)
-            if (!(((uint32_t)__builtin_amdgcn_readlane((int)needv, (int)(s_ >> 5)) >> (s_ & 31u)) & 1u)) {
+            if (!((need_word(s_ >> 5) >> (s_ & 31u)) & 1u)) {
                 verify_group(2 * s_, 0xFFFFu);
                 verify_group(2 * s_ + 1, 0xFFFFu);
             }
@@ -1006,7 +1010,7 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
                 for (uint32_t g_ = 0; g_ < 2 * ntiles; ++g_)
                     if (!((need >> g_) & 1u)) verify_group(g_, 0xFFFFu);
 #endif
-        } else if (streamed) { /* <= 1024 tiles: the 16-bit group numbers cannot run out within a pass */
+        } else if (streamed) { /* <= 4096 tiles: the 16-bit group numbers cannot run out within a pass */
             while (t < ntiles && !flush) {
                 const mirt_h8 a0 = pre0, a1 = pre1;
                 const uint32_t tn = next_needed(t + 1u);
@@ -1114,7 +1118,7 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
  * The price is that the waves are no longer free-running: every wave of the block must make every call with the same
  * number of barriers (MIRT_RING chunks + 1, a function of the scene alone), so render_body keeps idle waves in the loop
  * until the whole block is out of work (T::LOCKSTEP), and a wave without a ray still stages and waits. */
-#define MIRT_MX_CULL_TILES 1024u /* scenes beyond the LDS: the tile cull keeps one need word per 32 tiles in the lanes of a VGPR (<= 32 top tiles = 32 768 spheres) */
+#define MIRT_MX_CULL_TILES 4096u /* scenes beyond the LDS: the tile cull keeps one need word per 32 tiles in the lanes of two VGPRs (<= 128 top tiles = 131 072 spheres) */
 #ifndef MIRT_RING_TILES
 #define MIRT_RING_TILES 24u /* two chunks of 24 tiles = 96 KB: the operand area and the (unused, the scene is not resident) A / B areas behind it; 8 / 16 / 24 tiles: 119.5 / 116.0 / 114.0 ms on the 10 000-sphere frame */
 #endif
@@ -1161,25 +1165,6 @@ __device__ inline void trace_mx_ring(const DevScene<float>& sc, LDS& L, uint32_t
     };
     const uint32_t sub = lane >> 5;
     stage(0);
-    /* ---- tile cull (mx_cull 3): the top tiles behind the last tile hold a ball around each tile (row k of top tile j: tile
-     * 32 j + k), as for resident scenes (trace_mx); each wave fetches them from L1/L2 for itself - 2 KB per 32 tiles - while
-     * chunk 0 is on its way, and keeps the tiles its rays may touch as one 32-bit word per top tile in lane j of `needv`.  The
-     * chunks are staged for the whole block as before; a wave runs only its own tiles of each through the matrix pipe. */
-    const bool cull = sc.mx_cull == 3u;
-    uint32_t needv = 0xFFFFFFFFu;
-    if (cull && wave_live) {
-        const uint32_t ntop = (ntiles + 31u) / 32u; /* <= 32 (mx_cull_mode) */
-        const mirt_h8* G = (const mirt_h8*)sc.SM + (size_t)ntiles * 128u;
-        mirt_h8 p0 = G[lane], p1 = G[64u + lane];
-        for (uint32_t j = 0; j < ntop; ++j) {
-            const mirt_h8 a0 = p0, a1 = p1;
-            if (j + 1u < ntop) { p0 = G[(j + 1u) * 128u + lane]; p1 = G[(j + 1u) * 128u + 64u + lane]; }
-            const uint32_t wj = mx_need_word(a0, a1, bx0, bx1, by0, by1);
-            needv = lane == j ? wj : needv;
-            ++tiles_done;
-        }
-        pt.stamp(PH_OTHER);
-    }
     __syncthreads(); /* waits for the copies (vmcnt) and for the other waves: also fences the previous call's readers */
     uint32_t t = 0, cnt = 0, gbase = 0;
     for (uint32_t c = 0; c < nch; ++c) {
@@ -1191,19 +1176,7 @@ __device__ inline void trace_mx_ring(const DevScene<float>& sc, LDS& L, uint32_t
             t_end = t_end < ntiles ? t_end : ntiles;
             while (t < t_end) {
                 bool flush = false;
-                while (t < t_end && !flush) {
-                    if (cull) { /* on to the next tile of this wave's (wave-uniform: scalar code) */
-                        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)needv, (int)(t >> 5)) >> (t & 31u);
-                        const uint32_t t_next = word ? t + (uint32_t)__builtin_ctz(word) : (t | 31u) + 1u;
-#ifdef MIRT_VERIFY_BROAD
-                        for (uint32_t s_ = t; s_ < t_next && s_ < t_end; ++s_) { /* no sphere of a skipped tile may have an exact discriminant >= 0 */
-                            mx_verify_group(sc, ray, a_true, active, 2 * s_, 0xFFFFu);
-                            mx_verify_group(sc, ray, a_true, active, 2 * s_ + 1, 0xFFFFu);
-                        }
-#endif
-                        t = t_next;
-                        if (t >= t_end) break;
-                    }
+                for (; t < t_end && !flush; ++t) {
                     const mirt_h8 a0 = buf[(t - t0) * 128u + lane], a1 = buf[(t - t0) * 128u + 64u + lane];
                     uint32_t mx = 2 * t - gbase + sub, my = mx;
                     mx_tile(a0, a1, bx0, bx1, by0, by1, mx, my);
@@ -1215,9 +1188,7 @@ __device__ inline void trace_mx_ring(const DevScene<float>& sc, LDS& L, uint32_t
                     cnt += ((mx & my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
                     flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull;
                     ++tiles_done;
-                    ++t;
                 }
-                t = t < t_end ? t : t_end; /* the skip may have looked past the chunk: the next chunk starts at its first tile */
                 /* a full list, or 0x7FFF tiles behind the pass's first one (group numbers in the entries are 16 bit) */
                 if (flush || 2u * t - gbase >= 0xFFFEu) {
                     pt.stamp(PH_BROAD);
@@ -2181,21 +2152,19 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel_f64(DevSc
     if (sc.n_live <= MIRT_TINY_SCENE) render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane, att);
     else render_body(tr, sc, cam, part, rp, partial, stats, lane, att);
 }
-/* parity mode with the broad phase on the matrix pipe: f32 filter, exact f64 narrow phase and shading */
+/* parity mode with the broad phase on the matrix pipe: f32 filter, exact f64 narrow phase and shading.  RES: the operands are
+ * resident (<= MIRT_MX64_RECORDS sorted slots), else every wave streams its tiles; the host picks (launch_render) */
+template <bool RES>
 __global__ __launch_bounds__(MIRT_BLOCK, 3) void render_kernel_f64_mx(DevScene<double> sc, DevCamera<double> cam, DevPart part, RenderParams rp,
                                                                       double* __restrict__ partial, DevStats* __restrict__ stats, double* __restrict__ att) {
     __shared__ MxLds64 L;
     __shared__ LaunchParams<double> P;
     stage_params(&P, cam, part, rp);
     const bool res = L.fill(sc); /* ends with the block barrier */
+    if (res != RES) return;      /* never: the host launches <true> exactly for the scenes fill() makes resident */
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    if (res) {
-        TracerF64Mx<true> tr{sc, L, w};
-        render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane, att);
-    } else {
-        TracerF64Mx<false> tr{sc, L, w};
-        render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane, att);
-    }
+    TracerF64Mx<RES> tr{sc, L, w};
+    render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane, att);
 }
 /* MIRT_FLAG_BVH: latency-bound per-lane traversal, small blocks, as many waves as the registers allow */
 __global__ __launch_bounds__(MIRT_BLOCK) void render_kernel_f32_bvh(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
@@ -2248,8 +2217,10 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
 }
 
 /* the same with the broad phase on the matrix pipe (scenes whose coordinates fit the split-f16 operands); LDS = MxLdsSmall
- * for scenes of up to MIRT_MX_SMALL_RECORDS sorted slots (chosen by the host), MxLds otherwise */
-template <class LDS>
+ * for scenes of up to MIRT_MX_SMALL_RECORDS sorted slots, MxLds otherwise; RES: the scene is resident in the LDS layout, else
+ * every wave streams its tiles from L1/L2 (tile cull, scenes beyond the LDS).  The host picks the instantiation (launch_render);
+ * one tracer per kernel keeps the streaming loop's registers and code out of the resident kernels. */
+template <class LDS, bool RES>
 __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32_mx(DevScene<float> sc, DevCamera<float> cam, DevPart part, RenderParams rp,
                                                                        float* __restrict__ partial, DevStats* __restrict__ stats) {
     __shared__ LDS L;
@@ -2258,14 +2229,10 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
     LaunchParams<float>* P = reinterpret_cast<LaunchParams<float>*>(L.params);
     stage_params(P, cam, part, rp);
     const bool res = L.fill(sc); /* ends with the block barrier */
+    if (res != RES) return;      /* never: the host launches <.., true> exactly for the scenes fill() makes resident */
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    if (res) {
-        TracerF32Mx<true, LDS> tr{sc, L, w};
-        render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
-    } else {
-        TracerF32Mx<false, LDS> tr{sc, L, w};
-        render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
-    }
+    TracerF32Mx<RES, LDS> tr{sc, L, w};
+    render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
 }
 
 /* the same for scenes of more than MIRT_LDS_RECORDS sorted slots: operands through the block-wide LDS ring */
