@@ -135,7 +135,7 @@ typedef enum mirt_precision {
 /* Brute-force loop: take the matrix-pipe broad phase also for scenes below its size threshold (24 spheres), where the
  * vector-ALU loop is faster.  A tuning / test switch; the image does not depend on it. */
 #define MIRT_FLAG_MX_SMALL 16u
-/* Matrix-pipe brute-force loop, resident scenes (<= 1024 spheres): test every (ray, sphere) pair.  By default the kernel first
+/* Matrix-pipe brute-force loop, scenes of up to 131 072 spheres: test every (ray, sphere) pair.  By default the kernel first
  * tests, with the same contraction and margins, a ball around each tile of 32 spheres (the spheres are kept in a spatial order)
  * and skips the tiles that no ray of the wave can touch - the (id, t) of every ray, hence the image, is the same bit for bit;
  * mirt_stats.mx_tiles tells how many tiles were evaluated.  The flag switches the cull off (measurements: the all-pairs rate). */
