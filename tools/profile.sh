@@ -1,12 +1,13 @@
 #!/bin/bash
-# One-stop profile of bench.py on the GPU box: kernel-trace stats, SQ counters (3 passes), HBM bytes (2 passes).
+# One-stop profile of bench.py on the GPU box: kernel-trace stats (the driver's command: 20 steps after 5 warm-up steps, so that the few
+# slower launches on a cold chip weigh as little in the average as in bench.py's own), SQ counters (3 passes), HBM bytes (2 passes).
 # usage: tools/profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/{kernel_stats.csv,sq_pmc.txt,hbm.txt}
 tag=$1; shift
 BARGS="$*"
 root=$GRAFT_REPO_ROOT; [ -z "$root" ] && root=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $root
 out=gpurun_out/prof_$tag; mkdir -p $out
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o k -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras $BARGS > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o k -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras $BARGS > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
 cp $out/kt/k_kernel_stats.csv $out/kernel_stats.csv 2>/dev/null || find $out/kt -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 tools/pmc.sh $tag $BARGS > $out/sq_pmc.txt 2>&1 || { tail -5 $out/sq_pmc.txt; exit 1; }
 for c in FETCH_SIZE WRITE_SIZE; do
