@@ -17,6 +17,7 @@ lib = abi.load()
 scene, cam, name = bench.build_workload("balls1080p", 1920, 64, 50)
 cam.chunk_samples = int(os.environ.get("PROBE_CHUNK", "0"))  # mirt_opts.chunk_samples (0 = the library's choice)
 extra_flags = int(os.environ.get("PROBE_FLAGS", "0"))
+cam.group_chunks = int(os.environ.get("PROBE_G", "0"))  # mirt_opts.group_chunks (0 = the library's choice)
 S = dist.DEFAULT_STRIP_ROWS
 handles = [DeviceScene(scene.flat, 0) for _ in range(4)]
 streams = [torch.cuda.Stream() for _ in range(4)]
