@@ -261,15 +261,21 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+/* The uniforms of one camera ray (bounce 0) or one scatter (bounce b >= 1) of a sample: Philox4x32-10 blocks with the counter
+ * (pixel, sample, bounce, block).  fill() evaluates the blocks once - render_body makes ONE call per loop iteration in which a lane
+ * asks for the camera ray's blocks or for a scatter's, whichever it needs - and the dims*() accessors turn the words into uniforms. */
 template <class R> struct Draws;
 template <> struct Draws<double> {
-    uint32_t pixel, sample, bounce, k0, k1;
-    /* dims 2*blk and 2*blk+1 */
+    uint32_t o[12];
+    /* dims 2*blk and 2*blk+1 of block blk; a camera ray takes three blocks (five dims), a scatter two */
+    __device__ inline void fill(uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t k0, uint32_t k1, bool camera) {
+        philox4x32_10(pixel, sample, bounce, 0u, k0, k1, o);
+        philox4x32_10(pixel, sample, bounce, 1u, k0, k1, o + 4);
+        if (camera) philox4x32_10(pixel, sample, bounce, 2u, k0, k1, o + 8);
+    }
     __device__ inline void pair(uint32_t blk, double& a, double& b) const {
-        uint32_t o[4];
-        philox4x32_10(pixel, sample, bounce, blk, k0, k1, o);
-        a = (double)(((uint64_t)o[0] | ((uint64_t)o[1] << 32)) >> 11) * 0x1.0p-53;
-        b = (double)(((uint64_t)o[2] | ((uint64_t)o[3] << 32)) >> 11) * 0x1.0p-53;
+        a = (double)(((uint64_t)o[4 * blk] | ((uint64_t)o[4 * blk + 1] << 32)) >> 11) * 0x1.0p-53;
+        b = (double)(((uint64_t)o[4 * blk + 2] | ((uint64_t)o[4 * blk + 3] << 32)) >> 11) * 0x1.0p-53;
     }
     __device__ inline void dims0123(double& a, double& b, double& c, double& d) const { pair(0, a, b); pair(1, c, d); }
     __device__ inline void dims01234(double& a, double& b, double& c, double& d, double& e) const {
@@ -280,17 +286,14 @@ template <> struct Draws<double> {
     }
 };
 template <> struct Draws<float> {
-    uint32_t pixel, sample, bounce, k0, k1;
-    __device__ static inline float cvt(uint32_t w) { return (float)(w >> 8) * 0x1.0p-24f; }
-    __device__ inline void dims0123(float& a, float& b, float& c, float& d) const {
-        uint32_t o[4];
+    uint32_t o[4];
+    __device__ inline void fill(uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t k0, uint32_t k1, bool) {
         philox4x32_10(pixel, sample, bounce, 0u, k0, k1, o);
-        a = cvt(o[0]); b = cvt(o[1]); c = cvt(o[2]); d = cvt(o[3]);
     }
+    __device__ static inline float cvt(uint32_t w) { return (float)(w >> 8) * 0x1.0p-24f; }
+    __device__ inline void dims0123(float& a, float& b, float& c, float& d) const { a = cvt(o[0]); b = cvt(o[1]); c = cvt(o[2]); d = cvt(o[3]); }
     /* dims 0..4 out of ONE block: dim 4 = the low bytes of words 0..2 (24 bits) */
     __device__ inline void dims01234(float& a, float& b, float& c, float& d, float& e) const {
-        uint32_t o[4];
-        philox4x32_10(pixel, sample, bounce, 0u, k0, k1, o);
         a = cvt(o[0]); b = cvt(o[1]); c = cvt(o[2]); d = cvt(o[3]);
         e = (float)((o[0] & 0xFFu) | ((o[1] & 0xFFu) << 8) | ((o[2] & 0xFFu) << 16)) * 0x1.0p-24f;
     }

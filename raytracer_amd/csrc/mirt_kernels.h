@@ -1901,7 +1901,14 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
     unsigned long long drain_live = 0, drain_iters = 0, drain_c0 = 0; /* lanes with work at that moment; iterations after it */
 #endif
 
-    for (;;) {
+    /* One loop iteration = one ray segment for every lane that has a ray, then ONE Philox evaluation in which a lane asks for what
+     * it needs next - the uniforms of the scatter at the hit it just found, or those of the camera ray of the sample it is about
+     * to start (its last ray went to the sky, or it has just been dealt an item) - never both.  (Rounds 1 and 2 generated camera
+     * rays before the segment and scattered after it: two evaluations per iteration, since a wave holds lanes of both kinds.)  A
+     * lane whose path ends INSIDE the scatter (absorbed, depth limit) has no uniforms for a camera ray in hand: it sits out the
+     * next segment (need_ray) and starts its sample one iteration later - 0.2 % of the lane-iterations of the bench frame.  The
+     * counters are those of the reference-order loop, so every sample sees the same uniforms and the image is the same bit for bit. */
+    auto deal = [&]() {
         /* ---- deal work items to idle lanes ---------------------------------------------------------- */
         const unsigned long long idle = __ballot(!has_work);
         MIRT_DIAG(sc, DG_DEAL, !has_work && !(exhausted && q_next == q_end));
@@ -1969,6 +1976,26 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 need_ray = has_work;
             }
         }
+    };
+    auto start_sample = [&](const Draws<R>& dr) { /* camera ray of (pixel, sample): camera.rs:209-230 / 248-252 */
+        thr = {(R)1.0, (R)1.0, (R)1.0};
+        depth_left = cam.depth;
+        bounce = 0;
+        ray = aa ? ray_for(cam, lx, gy, dr) : primary_ray(cam, lx, gy);
+        need_ray = false;
+    };
+    deal();
+    pt.stamp(PH_QUEUE);
+    {
+        Draws<R> dr;
+        MIRT_DIAG(sc, DG_RAYGEN, need_ray);
+        if (need_ray) {
+            if (aa) dr.fill(pixel, sample, 0u, rp.k0, rp.k1, true);
+            start_sample(dr);
+        }
+    }
+    pt.stamp(PH_RAYGEN);
+    for (;;) {
 #ifdef MIRT_PHASE_TIMING
         if (exhausted) ++drain_iters;
 #endif
@@ -1987,25 +2014,15 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
         }
 #endif
         pt.stamp(PH_QUEUE);
-        /* ---- camera ray for lanes that start a sample (camera.rs:209-230 / 248-252) ------------------- */
-        MIRT_DIAG(sc, DG_RAYGEN, need_ray);
-        if (need_ray) {
-            thr = {(R)1.0, (R)1.0, (R)1.0};
-            depth_left = cam.depth;
-            bounce = 0;
-            Draws<R> dr{pixel, sample, 0u, rp.k0, rp.k1};
-            ray = aa ? ray_for(cam, lx, gy, dr) : primary_ray(cam, lx, gy);
-            need_ray = false;
-        }
-        pt.stamp(PH_RAYGEN);
-        /* ---- one ray segment for every lane of the wave ---------------------------------------------- */
+        /* ---- one ray segment for every lane of the wave that has a ray -------------------------------- */
+        const bool has_ray = has_work && !need_ray;
         Closest<R> best;
         bool seg_done; /* this lane's closest-hit query completed in this iteration */
         if constexpr (T::RESUMABLE) {
             /* Lanes of a wave need very different numbers of tree steps (2-5x the mean for the slowest), and a step costs
              * the same whether 64 lanes take it or 3.  So a query is suspended as soon as a good share of the wave's
              * lanes have finished theirs: those are shaded, given their next ray (or item), and join the rest again. */
-            if (has_work && !traversing) { /* a fresh ray: from the camera or from the last scatter */
+            if (has_ray && !traversing) { /* a fresh ray: from the camera or from the last scatter */
                 trav = {sc.bvh_root, 0u};
                 pbest = {(R)INFINITY, 0xFFFFFFFFu};
                 traversing = true;
@@ -2018,67 +2035,79 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
             traversing = traversing && !seg_done;
             best = pbest;
         } else {
-            tr.closest(lane, has_work, ray, (R)0.001, best, n_narrow, pt);
-            seg_done = has_work;
+            tr.closest(lane, has_ray, ray, (R)0.001, best, n_narrow, pt);
+            seg_done = has_ray;
         }
-        if (seg_done) {
-            ++n_seg;
-            bool done;
-            V3<R> radiance = {(R)0.0, (R)0.0, (R)0.0};
-            MIRT_DIAG(sc, DG_HIT, best.idx != 0xFFFFFFFFu);
-            MIRT_DIAG(sc, DG_SKY, best.idx == 0xFFFFFFFFu);
-            if (best.idx != 0xFFFFFFFFu) {
-                Hit<R> hit = tr.hit(best, ray);
-                ++bounce;
-                Draws<R> dr{pixel, sample, bounce, rp.k0, rp.k1};
-                V3<R> att;
-                RayT<R> nxt;
-                if (scatter(sc, tr.material_record(best.idx), ray, hit, dr, att, nxt)) {
-                    if constexpr (REF_ORDER) {
-                        const size_t o = (size_t)(bounce - 1u) * 3u * rp.att_lanes + att_lane;
-                        att_stack[o] = att.x;
-                        att_stack[o + rp.att_lanes] = att.y;
-                        att_stack[o + 2u * (size_t)rp.att_lanes] = att.z;
-                    } else {
-                        thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
-                    }
-                    ray = nxt;
-                    --depth_left;
-                    done = depth_left == 0; /* color(.., 0) = black */
-                } else {
-                    done = true; /* absorbed: black for the whole path (camera.rs:279) */
-                }
-            } else { /* sky: camera.rs:282-284 */
-                V3<R> ud = unit(ray.d);
-                R a = (R)0.5 * (ud.y + (R)1.0);
-                V3<R> sky = {(R)1.0 * ((R)1.0 - a) + (R)0.5 * a, (R)1.0 * ((R)1.0 - a) + (R)0.7 * a, (R)1.0 * ((R)1.0 - a) + (R)1.0 * a};
-                if constexpr (REF_ORDER) {
-                    radiance = sky;
-                    for (uint32_t b = bounce; b-- > 0u;) { /* att * color(scattered, depth - 1), innermost first (camera.rs:277) */
-                        const size_t o = (size_t)b * 3u * rp.att_lanes + att_lane;
-                        radiance = {att_stack[o] * radiance.x, att_stack[o + rp.att_lanes] * radiance.y, att_stack[o + 2u * (size_t)rp.att_lanes] * radiance.z};
-                    }
-                } else {
-                    radiance = {thr.x * sky.x, thr.y * sky.y, thr.z * sky.z};
-                }
-                done = true;
+        /* ---- rays that left the scene: sky (camera.rs:282-284), the sample is done --------------------- */
+        auto sample_done = [&](const V3<R>& radiance) {
+            acc = acc + radiance;
+            ++sample;
+            const bool more = sample < s_end; /* regenerate: this lane starts its next sample */
+            MIRT_DIAG(sc, DG_STORE, !more);
+            if (!more) {
+                size_t o = (size_t)item * 3;
+                partial[o] = acc.x;
+                partial[o + 1] = acc.y;
+                partial[o + 2] = acc.z;
             }
-            if (done) {
-                acc = acc + radiance;
-                ++sample;
-                if (sample < s_end) {
-                    need_ray = true; /* regenerate: this lane starts its next sample in the next iteration */
-                } else {
-                    MIRT_DIAG(sc, DG_STORE, true);
-                    size_t o = (size_t)item * 3;
-                    partial[o] = acc.x;
-                    partial[o + 1] = acc.y;
-                    partial[o + 2] = acc.z;
-                    has_work = false;
+            /* plain assignments: a store to "one flag or the other" made the compiler keep both in scratch memory */
+            need_ray = need_ray || more;
+            has_work = has_work && more;
+        };
+        const bool scat = seg_done && best.idx != 0xFFFFFFFFu; /* a hit: this lane scatters below */
+        if (seg_done) ++n_seg;
+        MIRT_DIAG(sc, DG_HIT, scat);
+        MIRT_DIAG(sc, DG_SKY, seg_done && !scat);
+        if (seg_done && !scat) {
+            V3<R> ud = unit(ray.d);
+            R a = (R)0.5 * (ud.y + (R)1.0);
+            V3<R> sky = {(R)1.0 * ((R)1.0 - a) + (R)0.5 * a, (R)1.0 * ((R)1.0 - a) + (R)0.7 * a, (R)1.0 * ((R)1.0 - a) + (R)1.0 * a};
+            V3<R> radiance;
+            if constexpr (REF_ORDER) {
+                radiance = sky;
+                for (uint32_t b = bounce; b-- > 0u;) { /* att * color(scattered, depth - 1), innermost first (camera.rs:277) */
+                    const size_t o = (size_t)b * 3u * rp.att_lanes + att_lane;
+                    radiance = {att_stack[o] * radiance.x, att_stack[o + rp.att_lanes] * radiance.y, att_stack[o + 2u * (size_t)rp.att_lanes] * radiance.z};
                 }
+            } else {
+                radiance = {thr.x * sky.x, thr.y * sky.y, thr.z * sky.z};
             }
+            sample_done(radiance);
         }
         pt.stamp(PH_SHADE);
+        deal(); /* lanes whose item is finished take the next one (and start its first sample below) */
+        pt.stamp(PH_QUEUE);
+        /* ---- the iteration's one Philox evaluation ------------------------------------------------------ */
+        const bool starts = need_ray && !scat; /* need_ray of a lane that scatters is set below: that lane waits an iteration */
+        Draws<R> dr;
+        if (scat || (starts && aa)) dr.fill(pixel, sample, scat ? bounce + 1u : 0u, rp.k0, rp.k1, !scat);
+        if (scat) {
+            Hit<R> hit = tr.hit(best, ray);
+            ++bounce;
+            V3<R> att;
+            RayT<R> nxt;
+            bool done;
+            if (scatter(sc, tr.material_record(best.idx), ray, hit, dr, att, nxt)) {
+                if constexpr (REF_ORDER) {
+                    const size_t o = (size_t)(bounce - 1u) * 3u * rp.att_lanes + att_lane;
+                    att_stack[o] = att.x;
+                    att_stack[o + rp.att_lanes] = att.y;
+                    att_stack[o + 2u * (size_t)rp.att_lanes] = att.z;
+                } else {
+                    thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
+                }
+                ray = nxt;
+                --depth_left;
+                done = depth_left == 0; /* color(.., 0) = black */
+            } else {
+                done = true; /* absorbed: black for the whole path (camera.rs:279) */
+            }
+            if (done) sample_done(V3<R>{(R)0.0, (R)0.0, (R)0.0});
+        }
+        pt.stamp(PH_SHADE);
+        MIRT_DIAG(sc, DG_RAYGEN, starts);
+        if (starts) start_sample(dr);
+        pt.stamp(PH_RAYGEN);
     }
 #ifdef MIRT_PHASE_TIMING
     if (lane == 0) {
