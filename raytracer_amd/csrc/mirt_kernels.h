@@ -1999,6 +1999,10 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
 #ifdef MIRT_PHASE_TIMING
         if (exhausted) ++drain_iters;
 #endif
+        /* every lane's path ended inside the last scatter (a depth limit of 1 does that in every iteration): the wave's reserved
+         * batch and the queue may still hold items - deal before deciding that the wave is done.  The lanes start their samples
+         * after the coming (for them empty) segment like any lane that ends in a scatter. */
+        if (__ballot(has_work) == 0ull) deal();
         if constexpr (tracer_lockstep<T>::value) {
             /* the waves of the block leave together: a wave that has run dry keeps calling closest() (for its barriers) */
             if (!__syncthreads_or(__ballot(has_work) != 0ull ? 1 : 0)) break;
@@ -2035,7 +2039,11 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
             traversing = traversing && !seg_done;
             best = pbest;
         } else {
-            tr.closest(lane, has_ray, ray, (R)0.001, best, n_narrow, pt);
+            /* no lane has a ray (all of them ended inside the last scatter): nothing to trace - except that a tracer whose waves
+             * move in step must keep its barriers */
+            best.t = (R)INFINITY;
+            best.idx = 0xFFFFFFFFu;
+            if (tracer_lockstep<T>::value || __ballot(has_ray) != 0ull) tr.closest(lane, has_ray, ray, (R)0.001, best, n_narrow, pt);
             seg_done = has_ray;
         }
         /* ---- rays that left the scene: sky (camera.rs:282-284), the sample is done --------------------- */
@@ -2054,11 +2062,15 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
             need_ray = need_ray || more;
             has_work = has_work && more;
         };
-        const bool scat = seg_done && best.idx != 0xFFFFFFFFu; /* a hit: this lane scatters below */
+        /* a hit with one bounce left: color(scattered, 0) is black whatever the scatter does (camera.rs:270, 277-279), so the path
+         * ends here - without the scatter and without its uniforms */
+        const bool hit_any = seg_done && best.idx != 0xFFFFFFFFu;
+        const bool scat = hit_any && depth_left != 1u; /* a hit: this lane scatters below */
         if (seg_done) ++n_seg;
         MIRT_DIAG(sc, DG_HIT, scat);
-        MIRT_DIAG(sc, DG_SKY, seg_done && !scat);
-        if (seg_done && !scat) {
+        MIRT_DIAG(sc, DG_SKY, seg_done && !hit_any);
+        if (hit_any && !scat) sample_done(V3<R>{(R)0.0, (R)0.0, (R)0.0});
+        if (seg_done && !hit_any) {
             V3<R> ud = unit(ray.d);
             R a = (R)0.5 * (ud.y + (R)1.0);
             V3<R> sky = {(R)1.0 * ((R)1.0 - a) + (R)0.5 * a, (R)1.0 * ((R)1.0 - a) + (R)0.7 * a, (R)1.0 * ((R)1.0 - a) + (R)1.0 * a};

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 
 from raytracer_amd import abi, presets
-from raytracer_amd.api import Camera, ImageTexture, Lambertian, Scene
+from raytracer_amd.api import Camera, ImageTexture, Lambertian, Scene, Sphere
 
 pytestmark = pytest.mark.gpu
 
@@ -72,6 +72,34 @@ def test_f64_radiance_bit_exact_depth_limits_and_no_aa(oracle, plain_balls, dept
         o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F64, seed=3, use_bvh=True, threads=8)
         assert cam.last_stats["segments"] == o_seg
         assert np.array_equal(bits(lin), bits(o_lin))
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F64])
+def test_waves_whose_lanes_all_end_in_the_scatter(oracle, prec):
+    """Round 3's loop deals work after the segment and evaluates Philox once; a lane whose path ends INSIDE the scatter
+    (absorbed) has to wait for the next iteration, and a wave in which every lane does so at once must still take what is left
+    of its reserved batch and of the queue (a first version left the loop there: frames with holes, found by the segment
+    count of a depth-1 render).  A ground that fills the view and absorbs 49 of 50 rays makes that the common case; depth
+    limits 1 and 2 end every path at a hit without a scatter.  Frames and segment counts against the oracle, all front ends."""
+    sc = Scene()
+    sc.add(Sphere.new_static(1000.0, (0.0, -1000.0, 0.0), Lambertian.new((0.8, 0.7, 0.6), 0.02)))
+    for k in range(40):
+        sc.add(Sphere.new_static(0.3, (-6.0 + 0.3 * k, 0.3, -2.0 + 0.1 * (k % 7)), Lambertian.new((0.3, 0.6, 0.9), 0.05)))
+    sc.build_bvh()
+    # 640 x 360 x 16 one-sample items = 3.7 M: beyond the queue's tail (2.1 M items dealt one per lane), so that waves hold reserved batches
+    for depth, spp, w in ((50, 16, 640), (1, 8, 160), (2, 4, 160)):
+        cam = Camera.build((0.0, 6.0, 4.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), w, 16.0 / 9.0, spp, math.radians(50.0), 7.0, 0.0, depth)
+        g = cam.pass_granularity(precision=prec)
+        if prec == abi.F32:
+            o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F32, seed=21, threads=8, spec_chunk=g)
+        else:
+            o_lin, _, o_seg, _ = oracle.render(sc.flat, cam.pod, abi.F64, seed=21, use_bvh=True, threads=8)
+        if depth == 1:
+            assert o_seg == cam.width * cam.height * spp
+        for accel in ((None, "valu", "bvh") if prec == abi.F32 else (None, "valu")):
+            lin, _ = cam.render_arrays(sc, precision=prec, seed=21, accel=accel)
+            assert cam.last_stats["segments"] == o_seg, (depth, accel)
+            assert np.array_equal(bits(lin), bits(o_lin)), (depth, accel)
 
 
 @pytest.mark.parametrize("accel", [None, "valu", "bvh"])
