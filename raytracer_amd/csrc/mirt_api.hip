@@ -60,6 +60,7 @@ struct mirt_scene {
     MxSet mx32, mx64;             /* balls around the f32 spheres (what the f32 kernels test) and around the f64 ones */
     mutable uint4* SM = nullptr;  /* operands and scale of the call being launched */
     mutable float mx_scale = 1.f;
+    float mx_drift[3] = {0.f, 0.f, 0.f}; /* common part of the shutter motion taken out of the matrix-pipe filter's balls (mirt_scene_create) */
     mutable uint32_t mx_cull = 0; /* this call may skip tiles by the top tile (resident scenes, not MIRT_FLAG_ALL_PAIRS) */
     DevStats* stats = nullptr; /* one per scene: launches on one scene handle are ordered one after the other (ev_busy) */
     mutable std::vector<void*> allocs; /* everything freed with the scene (mutable: operand copies are made on first use) */
@@ -453,6 +454,7 @@ template <class R> static DevScene<R> dev_scene(const mirt_scene* s, const Scene
     d.bvh = s->bvh; d.bvh_S = s->bvh_S; d.bvh_idx = s->bvh_idx; d.bvh_root = s->bvh_root;
     d.bvh_n_nodes = s->bvh_n_nodes; d.bvh_n_recs = s->bvh_n_recs; d.bvh_depth = s->bvh_depth;
     d.SM = s->SM; d.mx_scale = s->mx_scale; d.mx_cull = s->mx_cull;
+    for (int a = 0; a < 3; ++a) d.mx_drift[a] = s->mx_drift[a];
     d.dbg = s->stats ? &s->stats->broad_misses : nullptr;
     return d;
 }
@@ -930,6 +932,44 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
         balls.reserve(d->n_spheres);
         std::vector<MxBall> mxb(order.size(), MxBall{{0, 0, 0}, 0, false}); /* every sorted slot, for the matrix-pipe operands */
         std::vector<MxBall> mxb64(order.size(), MxBall{{0, 0, 0}, 0, false});
+        /* The drift of the matrix-pipe filter: a sphere's ball has to hold it for every shutter time, and in the scenes the
+         * reference builds the moving spheres all move the same way (main.rs:170-173: up, by 0 .. 0.5) - their common motion
+         * inflates every ball for nothing.  Take v = the midrange of the displacements (statics count as 0) out: the filter
+         * tests the ray with its origin at O - tm v against balls around c0 + tm (dc - v), tm in [0, 1] - the same relative
+         * geometry, radius r + |dc - v| / 2 instead of r + |dc| / 2 (a static sphere pays |v| / 2).  Kept only if it makes the
+         * sum of the cross-sections smaller.  The exact tests and the vector-ALU / tree records know nothing of it. */
+        {
+            double lo3[3] = {0, 0, 0}, hi3[3] = {0, 0, 0};
+            for (size_t k = 0; k < order.size(); ++k) {
+                if (order[k] == 0xFFFFFFFFu) continue;
+                const mirt_sphere& sp = d->spheres[order[k]];
+                if (!sp.moving) continue;
+                for (int a = 0; a < 3; ++a) {
+                    const double dca = (double)((float)sp.center1[a] - (float)sp.center0[a]);
+                    if (dca == dca && std::fabs(dca) < 1e30) { lo3[a] = std::min(lo3[a], dca); hi3[a] = std::max(hi3[a], dca); }
+                }
+            }
+            float v[3];
+            for (int a = 0; a < 3; ++a) v[a] = (float)(0.5 * (lo3[a] + hi3[a]));
+            double with = 0, without = 0;
+            for (size_t k = 0; k < order.size(); ++k) {
+                if (order[k] == 0xFFFFFFFFu) continue;
+                const mirt_sphere& sp = d->spheres[order[k]];
+                double l0 = 0, l1 = 0;
+                for (int a = 0; a < 3; ++a) {
+                    const double dca = sp.moving ? (double)((float)sp.center1[a] - (float)sp.center0[a]) : 0.0;
+                    l0 += dca * dca;
+                    l1 += (dca - v[a]) * (dca - v[a]);
+                }
+                const double r = sp.radius > 0.0 ? sp.radius : 0.0;
+                if (!(r < 1e30) || !(l0 < 1e60)) continue;
+                without += (r + 0.5 * std::sqrt(l0)) * (r + 0.5 * std::sqrt(l0)) / (1.0 + r * r); /* relative growth of the cross-section, so that one huge sphere does not decide */
+                with += (r + 0.5 * std::sqrt(l1)) * (r + 0.5 * std::sqrt(l1)) / (1.0 + r * r);
+            }
+            if (with < without) for (int a = 0; a < 3; ++a) s->mx_drift[a] = v[a];
+        }
+        const double vd[3] = {(double)s->mx_drift[0], (double)s->mx_drift[1], (double)s->mx_drift[2]};
+        const double vl = std::sqrt(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]);
         for (size_t k = 0; k < order.size(); ++k) {
             if (order[k] == 0xFFFFFFFFu) { S[k].x = S[k].y = S[k].z = 0.f; S[k].w = INFINITY; continue; }
             const mirt_sphere& sp = d->spheres[order[k]];
@@ -955,17 +995,25 @@ int mirt_scene_create(const mirt_scene_desc* d, int device, mirt_scene** out) {
             wf = std::nextafterf(wf, -INFINITY);
             S[k].x = Mf[0]; S[k].y = Mf[1]; S[k].z = Mf[2]; S[k].w = wf;
             balls.push_back(BallRec{{(double)Mf[0], (double)Mf[1], (double)Mf[2]}, rho, (uint32_t)k});
-            mxb[k] = MxBall{{(double)Mf[0], (double)Mf[1], (double)Mf[2]}, rho, true};
-            {   /* the same centre for the f64 kernels, whose sphere is the description's own: c0 + tm (c1 - c0) in double */
-                double dcd[3] = {0, 0, 0}, off2 = 0, dcl2 = 0;
+            {   /* the matrix-pipe filter's balls: around the motion relative to the drift, c0 + tm (dc - v) */
+                float Mx[3];
+                double rl = 0;
+                for (int a = 0; a < 3; ++a) { Mx[a] = (float)(c0[a] + 0.5 * (dc[a] - vd[a])); rl += (dc[a] - vd[a]) * (dc[a] - vd[a]); }
+                rl = std::sqrt(rl);
+                const double Mxl = std::sqrt((double)Mx[0] * Mx[0] + (double)Mx[1] * Mx[1] + (double)Mx[2] * Mx[2]);
+                /* sphere + half the relative travel + rounding of the centre, of fma(tm, dc, c0) and of the travel itself */
+                mxb[k] = MxBall{{(double)Mx[0], (double)Mx[1], (double)Mx[2]}, r + 0.5 * rl + 8.0 * eps * (Mxl + dcl + vl + r), true};
+                /* the same centre for the f64 kernels, whose sphere is the description's own: c0 + tm (c1 - c0) in double */
+                double off2 = 0, dcl2 = 0, rl2 = 0;
                 for (int a = 0; a < 3; ++a) {
-                    if (sp.moving) dcd[a] = sp.center1[a] - sp.center0[a];
-                    const double off = sp.center0[a] + 0.5 * dcd[a] - (double)Mf[a];
+                    const double dcd = sp.moving ? sp.center1[a] - sp.center0[a] : 0.0;
+                    const double off = sp.center0[a] + 0.5 * (dcd - vd[a]) - (double)Mx[a];
                     off2 += off * off;
-                    dcl2 += dcd[a] * dcd[a];
+                    dcl2 += dcd * dcd;
+                    rl2 += (dcd - vd[a]) * (dcd - vd[a]);
                 }
                 const double rd = sp.radius > 0.0 ? sp.radius : 0.0, dl = std::sqrt(dcl2);
-                mxb64[k] = MxBall{{(double)Mf[0], (double)Mf[1], (double)Mf[2]}, rd + 0.5 * dl + std::sqrt(off2) + 1e-12 * (Ml + dl + rd), true};
+                mxb64[k] = MxBall{{(double)Mx[0], (double)Mx[1], (double)Mx[2]}, rd + 0.5 * std::sqrt(rl2) + std::sqrt(off2) + 1e-12 * (Mxl + dl + vl + rd), true};
             }
         }
         if ((rc = upload(s, S, &s->S))) { mirt_scene_destroy(s); return rc; }

@@ -672,7 +672,12 @@ __device__ inline void mx_ray_operands(const DevScene<R>& sc, const RayT<R>& ray
                                        mirt_h8& by1) {
         const R inv = filter_rsq(a_true.a);
         const V3<float> Dn = {(float)(ray.d.x * inv), (float)(ray.d.y * inv), (float)(ray.d.z * inv)};
-        const V3<float> O = {(float)(ray.o.x * (R)sc.mx_scale), (float)(ray.o.y * (R)sc.mx_scale), (float)(ray.o.z * (R)sc.mx_scale)};
+        /* the drift: every sphere is tested where it is at the ray's time MINUS tm * mx_drift, so the origin moves by the same
+         * amount (one rounding per component, <= eps |O|: a line displaced by that much costs 2 eps (|M| + |O|)^2 of the spare
+         * margin, see above); the balls on the host are built around the spheres' motion relative to the drift */
+        const R tmn = -ray.tm;
+        const V3<float> O = {(float)((ray.o.x + tmn * (R)sc.mx_drift[0]) * (R)sc.mx_scale), (float)((ray.o.y + tmn * (R)sc.mx_drift[1]) * (R)sc.mx_scale),
+                             (float)((ray.o.z + tmn * (R)sc.mx_drift[2]) * (R)sc.mx_scale)};
         const float k1 = __builtin_fmaf(Dn.z, O.z, __builtin_fmaf(Dn.y, O.y, Dn.x * O.x));
         const float o2 = __builtin_fmaf(O.z, O.z, __builtin_fmaf(O.y, O.y, O.x * O.x));
         const float k2 = o2 * MIRT_MX_SHRINK - __builtin_fmaf(MIRT_MX_FLOOR_LIN, filter_sqrt(o2), MIRT_MX_FLOOR_ABS);
