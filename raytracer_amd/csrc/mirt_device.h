@@ -189,6 +189,7 @@ template <class R> struct DevScene {
      * in the scene's power-of-two scale mx_scale (NULL when the scene does not qualify) */
     const uint4* SM;
     float mx_scale;
+    uint32_t n_big, big_idx[4]; /* sorted slots of the spheres the matrix-pipe filter leaves out (MIRT_MX_BIG: far larger than the rest of the scene - the ground): every ray tests them exactly, directly */
     float mx_drift[3]; /* the common part of the spheres' shutter motion (world units): the filter tests the ray with its origin moved by -tm * mx_drift against balls around what is left of each sphere's motion (mirt_scene_create) */
     uint32_t mx_cull; /* resident scenes: tile `ntiles` of SM is the top tile (a ball around each tile's balls) and trace_mx may skip tiles by it */
 };

@@ -883,6 +883,9 @@ __device__ inline void mx_verify_group(const DevScene<R>& sc, const RayT<R>& ray
     for (uint32_t k_ = 0; k_ < 16; ++k_) {
         const uint32_t i_ = g * 16 + k_;
         if (i_ >= sc.n) break;
+        bool big_ = false; /* left out of the filter on purpose: tested directly by every ray */
+        for (uint32_t b_ = 0; b_ < sc.n_big; ++b_) big_ = big_ || sc.big_idx[b_] == i_;
+        if (big_) continue;
         typename Vec4<R>::type sa_ = sc.A[i_];
         V3<R> C_ = {sa_.x, sa_.y, sa_.z};
         if (i_ >= sc.n_static) {
@@ -921,7 +924,30 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
     if (!RES) { pre0 = SM[lane]; pre1 = SM[64 + lane]; }
     constexpr bool BALANCED = RES && sizeof(R) == 4 && mx_pair_cap<LDS>::value > 0;
     uint32_t ring_head = 0, ring_tail = 0;
-    if constexpr (BALANCED) L.slot[w][lane] = MIRT_KEY_NONE;
+    /* the spheres the filter leaves out (far larger than the rest of the scene - the ground of the reference's scenes, which
+     * every line meets and which alone would set the scale of the f16 operands): every ray tests them exactly, here, with no
+     * candidate list in between; the closest hit is the minimum over all exact tests in any order (narrow_balanced) */
+    if constexpr (BALANCED) {
+        unsigned long long k0 = MIRT_KEY_NONE;
+        if (active)
+            for (uint32_t b = 0; b < sc.n_big; ++b) {
+                const uint32_t i = sc.big_idx[b];
+                const unsigned long long k = pair_key(sc, GeomLdsT<LDS>{L}, i, (uint32_t)L.oid[i], ray, a_true, tmin);
+                k0 = k < k0 ? k : k0;
+                ++narrow_count;
+            }
+        L.slot[w][lane] = k0;
+    } else if (active) {
+        for (uint32_t b = 0; b < sc.n_big; ++b) {
+            if constexpr (LDS::GEOM_LDS) {
+                if (RES) narrow_test(sc, GeomLdsT<LDS>{L}, sc.big_idx[b], ray, a_true, tmin, best);
+                else narrow_test(sc, GeomGlobal<R>{sc}, sc.big_idx[b], ray, a_true, tmin, best);
+            } else {
+                narrow_test(sc, GeomGlobal<R>{sc}, sc.big_idx[b], ray, a_true, tmin, best);
+            }
+            ++narrow_count;
+        }
+    }
     /* ---- tile cull (resident scenes): which tiles can ANY ray of this wave touch?  The top tile behind the last one holds a
      * ball around each tile's balls; one pass of the same contraction over it gives every lane the tiles its ray may meet, the
      * wave ORs them, and the loop below skips the rest.  A skipped tile has no candidate for any lane (its ball test is as
@@ -1066,20 +1092,11 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
             flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull; /* no room for another tile */
         }
         }
-        const bool last = packed ? rem == 0u : t >= ntiles;
         prio_other();
         pt.stamp(PH_BROAD);
         MIRT_DIAG(sc, DG_PASS, active);
         if constexpr (BALANCED) {
             narrow_balanced(sc, L, w, lane, ent2, gbase, cnt, ray, a_true, tmin, ring_head, ring_tail, narrow_count);
-            if (last) { /* the last pass: run what is left and collect this lane's result */
-                narrow_drain(sc, L, w, lane, ray, a_true, tmin, ring_head, ring_tail);
-                const unsigned long long ks = L.slot[w][lane];
-                if (ks != MIRT_KEY_NONE) {
-                    best.t = __uint_as_float((uint32_t)(ks >> 32));
-                    best.idx = (uint32_t)ks & 0xFFFFu;
-                }
-            }
             pt.stamp(PH_NARROW);
         } else
         /* ---- narrow phase: as in trace_cons ---- */
@@ -1111,7 +1128,17 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
             pt.stamp(PH_NARROW);
         }
     }
-    /* a wave whose rays can touch no tile at all (packed: need == 0) never enters the loop: best stays "no hit" */
+    /* after the last pass (or after none: a wave whose rays can touch no tile at all never enters the loop): run what is left in
+     * the ring and collect this lane's result - the directly tested spheres' included */
+    if constexpr (BALANCED) {
+        narrow_drain(sc, L, w, lane, ray, a_true, tmin, ring_head, ring_tail);
+        const unsigned long long ks = L.slot[w][lane];
+        if (ks != MIRT_KEY_NONE) {
+            best.t = __uint_as_float((uint32_t)(ks >> 32));
+            best.idx = (uint32_t)ks & 0xFFFFu;
+        }
+        pt.stamp(PH_NARROW);
+    }
 }
 
 /* ---- f32, scenes that do not fit the LDS: the sphere operands through a block-wide LDS ring ----------------
@@ -1137,6 +1164,11 @@ __device__ inline void trace_mx_ring(const DevScene<float>& sc, LDS& L, uint32_t
     best.t = INFINITY;
     best.idx = 0xFFFFFFFFu;
     const RayA<float> a_true = ray_a(ray.d);
+    if (active)
+        for (uint32_t b = 0; b < sc.n_big; ++b) { /* the spheres the filter leaves out: see trace_mx */
+            narrow_test(sc, GeomGlobal<float>{sc}, sc.big_idx[b], ray, a_true, tmin, best);
+            ++narrow_count;
+        }
     const uint32_t ntiles = (sc.n + 31) / 32, nch = (ntiles + MIRT_RING_TILES - 1u) / MIRT_RING_TILES;
     const bool wave_live = __ballot(active) != 0ull; /* a wave without rays only stages and keeps the barriers */
     uint2(*ent2)[MIRT_WAVE] = reinterpret_cast<uint2(*)[MIRT_WAVE]>(L.ent[w]);
