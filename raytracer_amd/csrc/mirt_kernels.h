@@ -921,12 +921,12 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
     const uint32_t sub = lane >> 5;
     uint32_t t = 0;
     mirt_h8 pre0 = {}, pre1 = {};
-    if (!RES) { pre0 = SM[lane]; pre1 = SM[64 + lane]; }
+    if (!RES && sc.mx_cull != 1u && sc.mx_cull != 3u) { pre0 = SM[lane]; pre1 = SM[64 + lane]; } /* no cull: tile 0 first (with the cull: the first needed tile, below) */
     constexpr bool BALANCED = RES && sizeof(R) == 4 && mx_pair_cap<LDS>::value > 0;
     uint32_t ring_head = 0, ring_tail = 0;
     /* the spheres the filter leaves out (far larger than the rest of the scene - the ground of the reference's scenes, which
-     * every line meets and which alone would set the scale of the f16 operands): every ray tests them exactly, here, with no
-     * candidate list in between; the closest hit is the minimum over all exact tests in any order (narrow_balanced) */
+     * every line meets): every ray tests them exactly, here, with no candidate list in between; the closest hit is the minimum
+     * over all exact tests in any order (narrow_balanced) */
     if constexpr (BALANCED) {
         unsigned long long k0 = MIRT_KEY_NONE;
         if (active)
