@@ -573,7 +573,10 @@ def main():
                 "frames_in_flight": depth,
                 "seed": args.seed,
                 "closest_hit": ["brute-force LDS tile loop, broad phase on the vector ALU",
-                                "brute-force LDS tile loop, the whole broad-phase test as one split-f16 contraction on the matrix pipe (two chained MFMAs per 32 rays x 32 spheres), exact narrow phase on the vector ALU",
+                                "brute-force tile loop, the whole broad-phase test as one split-f16 contraction on the matrix pipe (two chained MFMAs per 32 rays x 32 spheres), "
+                                "only for the tiles of spatially ordered spheres some ray of the wave can touch (a ball per (half) tile goes through the same contraction first; "
+                                "MIRT_FLAG_ALL_PAIRS = every tile: `all_pairs`); spheres far larger than the rest (the ground) tested exactly by every ray; exact narrow phase on the "
+                                "vector ALU, balanced across the wave; same (id, t) for every ray as the all-VALU kernel",
                                 "bounding-ball tree (MIRT_FLAG_BVH)", "brute-force tile loop, f64",
                                 "brute-force tile loop, f64: f32 broad phase on the matrix pipe, exact f64 narrow phase and shading",
                                 "exact test on every sphere, no broad phase (scenes of a handful of spheres)"][kind],
