@@ -442,3 +442,61 @@ def test_tile_cull_lanes_that_keep_every_record(oracle, prec):
         for flags in (abi.FLAG_ALL_PAIRS, abi.FLAG_VALU_BROAD):
             assert res[0][3] == res[flags][3]
             assert np.array_equal(res[0][2].view(np.uint8), res[flags][2].view(np.uint8)), flags
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F64])
+def test_drift_and_directly_tested_spheres(oracle, prec):
+    """Round 3: the matrix-pipe filter takes the common part of the spheres' shutter motion out of its balls (the ray's origin
+    moves instead) and leaves spheres far larger than the rest of the scene to an exact test by every ray.  Scenes built to lean
+    on both: (a) a floor AND a wall of radius 3 000 / 2 500 (two directly tested spheres) under 220 small spheres that all move
+    along one diagonal; (b) no giant at all, half the spheres static, the others moving in opposite directions (the midrange of
+    the displacements is then 0 in one axis and the drift only half helps); (c) a MOVING giant.  Hit maps against the oracle and
+    the vector-ALU kernel, frames against the vector-ALU kernel and MIRT_FLAG_ALL_PAIRS, bit for bit."""
+    rng = np.random.default_rng(9)
+    mats = [Lambertian.new((0.7, 0.6, 0.5), 0.9), Metal.new((0.9, 0.8, 0.7), 0.05), Dielectric.new(1.5)]
+    scenes = []
+    sc = Scene()
+    sc.add(Sphere.new_static(3000.0, (0.0, -3000.0, 0.0), mats[0]))
+    sc.add(Sphere.new_static(2500.0, (0.0, 0.0, -2510.0), mats[1]))
+    for k in range(220):
+        c = rng.uniform(-9, 9, 3) * np.array([1.0, 0.0, 1.0]) + np.array([0.0, 0.25, 0.0])
+        sc.add(Sphere.new(0.25, tuple(c), tuple(c + np.array([1.0, 0.5, 0.0]) * rng.uniform(0.0, 0.8)), mats[k % 3]))
+    sc.build_bvh()
+    scenes.append(("two giants, one diagonal", sc, Camera.build((10.0, 4.0, 14.0), (0.0, 0.5, 0.0), None, 160, 1.6, 3, math.radians(45.0), 16.0, math.radians(0.3), 12)))
+    sc = Scene()
+    for k in range(300):
+        c = rng.uniform(-7, 7, 3)
+        if k % 2:
+            sc.add(Sphere.new_static(0.3, tuple(c), mats[k % 3]))
+        else:
+            sc.add(Sphere.new(0.3, tuple(c), tuple(c + np.array([0.0, 1.0 if k % 4 else -1.0, 0.3]) * rng.uniform(0.2, 0.9)), mats[k % 3]))
+    sc.build_bvh()
+    scenes.append(("opposite motions", sc, Camera.build((0.0, 3.0, 22.0), (0.0, 0.0, 0.0), None, 128, 1.0, 3, math.radians(40.0), 22.0, 0.0, 12)))
+    sc = Scene()
+    sc.add(Sphere.new(1500.0, (0.0, -1500.0, 0.0), (0.0, -1500.5, 0.0), mats[0]))
+    for k in range(150):
+        c = rng.uniform(-6, 6, 3) * np.array([1.0, 0.0, 1.0]) + np.array([0.0, 0.3, 0.0])
+        sc.add(Sphere.new(0.3, tuple(c), tuple(c + np.array([0.0, 0.4, 0.0])), mats[k % 3]))
+    sc.build_bvh()
+    scenes.append(("a moving giant", sc, Camera.build((0.0, 5.0, 15.0), (0.0, 0.0, 0.0), None, 128, 1.0, 3, math.radians(45.0), 15.0, 0.0, 12)))
+    lib = abi.load()
+    for name, sc, cam in scenes:
+        assert cam.closest_hit_kind(sc, precision=prec) in ("matrix", "f64-matrix"), name
+        ds = sc.device_scene(0)
+        H, W = cam.height, cam.width
+        o_ids, o_t = oracle.primary_hits(sc.flat, cam.pod, prec)
+        res = {}
+        for flags in (0, abi.FLAG_ALL_PAIRS, abi.FLAG_VALU_BROAD):
+            o = cam.opts(precision=prec, seed=6, flags=flags)
+            ids = np.empty((H, W), np.uint32)
+            t = np.empty((H, W), np.float64 if prec == abi.F64 else np.float32)
+            abi.check(lib.mirt_primary_hits(ds.handle, C.byref(cam.pod), C.byref(o), ids.ctypes.data, t.ctypes.data))
+            lin = np.empty((H, W, 3), t.dtype)
+            st = abi.MirtStats()
+            abi.check(lib.mirt_render(ds.handle, C.byref(cam.pod), C.byref(o), lin.ctypes.data, None, C.byref(st)))
+            res[flags] = (lin, st.segments)
+            assert np.array_equal(ids, o_ids), (name, flags)
+            assert np.array_equal(t[ids != 0xFFFFFFFF], o_t[ids != 0xFFFFFFFF]), (name, flags)
+        for flags in (abi.FLAG_ALL_PAIRS, abi.FLAG_VALU_BROAD):
+            assert res[0][1] == res[flags][1], (name, flags)
+            assert np.array_equal(res[0][0].view(np.uint8), res[flags][0].view(np.uint8)), (name, flags)
