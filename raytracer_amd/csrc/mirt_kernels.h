@@ -2230,10 +2230,13 @@ __global__ __launch_bounds__(MIRT_BLOCK, MIN_WAVES) void render_kernel_f64(DevSc
     if (sc.n_live <= MIRT_TINY_SCENE) render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane, att);
     else render_body(tr, sc, cam, part, rp, partial, stats, lane, att);
 }
+#ifndef MIRT_F64MX_BLOCKS
+#define MIRT_F64MX_BLOCKS 3 /* 4-wave blocks per CU the register budget is set for: 168 VGPRs, 46-66 spilled; measured 2 (256 VGPRs, no spills) / 3 / 4 (128): bench frame 23.9 / 22.5 / 40.5 ms, 10 000 spheres 42.9 / 36.6 / 84.4 ms (tools/f64_blocks_ab.sh) */
+#endif
 /* parity mode with the broad phase on the matrix pipe: f32 filter, exact f64 narrow phase and shading.  RES: the operands are
  * resident (<= MIRT_MX64_RECORDS sorted slots), else every wave streams its tiles; the host picks (launch_render) */
 template <bool RES>
-__global__ __launch_bounds__(MIRT_BLOCK, 3) void render_kernel_f64_mx(DevScene<double> sc, DevCamera<double> cam, DevPart part, RenderParams rp,
+__global__ __launch_bounds__(MIRT_BLOCK, MIRT_F64MX_BLOCKS) void render_kernel_f64_mx(DevScene<double> sc, DevCamera<double> cam, DevPart part, RenderParams rp,
                                                                       double* __restrict__ partial, DevStats* __restrict__ stats, double* __restrict__ att) {
     __shared__ MxLds64 L;
     __shared__ LaunchParams<double> P;
