@@ -662,8 +662,9 @@ __device__ inline void mx_split(float x, _Float16& hi, _Float16& lo) {
     asm volatile("" : "+v"(x));
     hi = (_Float16)x;
     asm volatile("" : "+v"(hi));
-    lo = (_Float16)(x - (float)hi);
-    asm volatile("" : "+v"(lo));
+    /* lo = f16(x - hi): the difference is exact in binary32, so there is one rounding, to f16, however it is computed - and
+     * v_fma_mixlo_f16 (f32 x * 1.0 - f16 hi, result rounded to f16) is ONE instruction where cvt, sub, cvt are three */
+    asm volatile("s_nop 0\n\tv_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x), "v"(hi)); /* s_nop: the wait state the compiler puts between v_cvt_f16_f32 and a reader of its result (it does not look inside asm) */
 }
 /* The ray side of the contraction: the ten coefficients of q, split, packed and exchanged between the half-waves (see the
  * K-slot table above).  bx0 / bx1: B operands of the two chained MFMAs for rays 0-31, by0 / by1 for rays 32-63. */
@@ -706,7 +707,7 @@ __device__ inline void mx_ray_operands(const DevScene<R>& sc, const RayT<R>& ray
         {
             _Float16 h, m, l;
             mx_split(cf[9], h, m);
-            l = (_Float16)((cf[9] - (float)h) - (float)m); /* both differences are exact in f32 */
+            asm volatile("s_nop 0\n\tv_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(cf[9] - (float)h), "v"(m)); /* both differences are exact in f32 */
             rv[27] = h; rv[28] = m; rv[29] = l;
             rv[30] = rv[31] = (_Float16)-1.0f;
         }
