@@ -1016,25 +1016,33 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
         const uint32_t gbase = packed ? 0u : 2 * t;
         bool flush = false;
         if (packed) {
-            const uint32_t row = lane & 31u, from_b = (row >> 2) & 1u;
+            /* The vector ALU's issue slots are what the kernel runs out of, so everything in this loop that is the same for all
+             * lanes is kept on the scalar unit: the rows of MFMA sub-block 0 come from half tile ha, those of sub-block 1 from hb -
+             * both wave-uniform - at (h >> 1) * 128 + (h & 1) * 4 records behind the lane's own constant place in a tile, which is
+             * place(ha) + (this lane reads hb ? place(hb) - place(ha) : 0): one AND and one three-operand add per lane. */
+            const uint32_t row = lane & 31u;
+            const uint32_t lane_at = (lane & 32u) + (row & ~4u);
+            uint32_t from_b = (row & 4u) ? 0xFFFFFFFFu : 0u, in_sub1 = sub ? 0xFFFFFFFFu : 0u;
+            asm volatile("" : "+v"(from_b), "+v"(in_sub1)); /* masks, not conditions: the compiler turns `mask & x` back into a move and a select otherwise */
+            uint32_t in_pass = 0; /* tiles of this pass so far (wave-uniform): cnt <= in_pass, so the list cannot be full before it is */
             while (rem != 0u && !flush) {
                 const uint32_t ha = (uint32_t)__builtin_ctz(rem);
-                rem &= rem - 1u;
+                rem ^= 1u << ha;
                 const bool two = rem != 0u;
                 const uint32_t hb = two ? (uint32_t)__builtin_ctz(rem) : ha;
-                rem &= rem - 1u; /* 0 stays 0 */
-                const uint32_t h = from_b ? hb : ha;
-                const uint32_t at = (h >> 1) * 128u + (lane & 32u) + ((row & ~4u) | ((h & 1u) << 2));
-                uint32_t mx = sub ? hb : ha, my = mx;
+                rem &= ~(two ? 1u << hb : 0u); /* (rem & (rem - 1) twice made the compiler take the borrow of rem - 1 through the vector ALU) */
+                const uint32_t at_a = (ha >> 1) * 128u + ((ha & 1u) << 2), at_b = (hb >> 1) * 128u + ((hb & 1u) << 2);
+                const uint32_t at = lane_at + at_a + (from_b & (at_b - at_a));
+                uint32_t mx = ha + (in_sub1 & (hb - ha)), my = mx;
                 mx_tile(SM[at], SM[at + 64], bx0, bx1, by0, by1, mx, my);
-                if (!two) my |= 0xFFFFu; /* the odd one out: the rows of sub 1 were a second copy of ha */
+                my |= two ? 0u : 0xFFFFu; /* the odd one out: the rows of sub 1 were a second copy of ha */
 #ifdef MIRT_VERIFY_BROAD
                 verify_group(ha, mx);
                 if (two) verify_group(hb, my);
 #endif
                 ent2[cnt][lane] = make_uint2(mx, my);
                 cnt += ((mx & my & 0xFFFFu) != 0xFFFFu) ? 1u : 0u;
-                flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull;
+                if (++in_pass > LDS::LDS_ENT_CAP / 2 - 1) flush = __ballot(cnt > LDS::LDS_ENT_CAP / 2 - 1) != 0ull;
                 ++tiles_done;
             }
 #ifdef MIRT_VERIFY_BROAD
