@@ -253,8 +253,15 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         }
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+#if defined(__HIP_DEVICE_COMPILE__)
+        /* a ^ b ^ c as ONE three-input boolean instruction (v_bitop3_b32, truth table 0x96) instead of two v_xor_b32: 20 vector-ALU
+         * instructions less per evaluation, and the kernels evaluate this once per loop iteration */
+        uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+        uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+#else
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
         uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+#endif
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;

@@ -1706,8 +1706,8 @@ template <class R> __device__ inline V3<R> refract(V3<R> uv, V3<R> n, R e) { /* 
  * The bounce's Philox block is evaluated ONCE, before the material switch: a wave usually holds lanes of all three
  * materials, and divergent branches that each called the generator would run it up to three times. */
 template <class R>
-__device__ inline bool scatter(const DevScene<R>& sc, const DevMaterial<R>& m, const RayT<R>& rin, const Hit<R>& hit, const Draws<R>& dr, V3<R>& att,
-                               RayT<R>& out) {
+__device__ inline bool scatter(const DevScene<R>& sc, const DevMaterial<R>& m, const V3<R>& rin_d, const Hit<R>& hit, const Draws<R>& dr, V3<R>& att,
+                               V3<R>& out_d) { /* the scattered ray starts at hit.p at the incoming ray's time (the caller's business): only its direction comes from here */
     R ua, ub, uc, ud; /* dims 0..3 of this bounce */
     dr.dims0123(ua, ub, uc, ud);
     if (m.kind == MIRT_MAT_LAMBERTIAN) { /* material.rs:59-84; dims: 0 = absorb test, 1..3 = vector */
@@ -1716,16 +1716,16 @@ __device__ inline bool scatter(const DevScene<R>& sc, const DevMaterial<R>& m, c
         V3<R> dir = hit.n + unit(V3<R>{ub, uc, ud}); /* positive-octant quirk of point3.rs:88-93 */
         const R e = (R)1e-8;
         if (m_fabs(dir.x) < e && m_fabs(dir.y) < e && m_fabs(dir.z) < e) dir = hit.n;
-        out = {hit.p, dir, rin.tm};
+        out_d = dir;
         att = lambertian_attenuation(sc, m, hit);
         return true;
     }
     if (m.kind == MIRT_MAT_METAL) { /* material.rs:97-114; dims 0..2 = vector */
         MIRT_DIAG(sc, DG_METAL, true);
         MIRT_DIAG(sc, DG_FUZZ, m.has_fuzz != 0);
-        V3<R> refl = reflect(rin.d, hit.n);
+        V3<R> refl = reflect(rin_d, hit.n);
         if (m.has_fuzz) refl = unit(refl) + unit(V3<R>{ua, ub, uc}) * m.fuzz;
-        out = {hit.p, refl, rin.tm};
+        out_d = refl;
         att = m.albedo;
         return !m.has_fuzz || dot(refl, hit.n) > (R)0.0;
     }
@@ -1734,13 +1734,12 @@ __device__ inline bool scatter(const DevScene<R>& sc, const DevMaterial<R>& m, c
     MIRT_DIAG(sc, DG_GLASS, true);
     att = {(R)1.0, (R)1.0, (R)1.0};
     R ri = hit.front ? (R)1.0 / m.ior : m.ior;
-    V3<R> udir = unit(rin.d);
+    V3<R> udir = unit(rin_d);
     R cos_theta = m_fmin(dot(-udir, hit.n), (R)1.0);
     R sin_theta = m_sqrt((R)1.0 - cos_theta * cos_theta);
     bool refl = ri * sin_theta > (R)1.0;
     if (!refl) refl = schlick(cos_theta, ri) > ua;
-    V3<R> dir = refl ? reflect(udir, hit.n) : refract(udir, hit.n, ri);
-    out = {hit.p, dir, rin.tm};
+    out_d = refl ? reflect(udir, hit.n) : refract(udir, hit.n, ri);
     return true;
 }
 
@@ -2142,10 +2141,14 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
         if (scat) {
             Hit<R> hit = tr.hit(best, ray);
             ++bounce;
-            V3<R> att;
-            RayT<R> nxt;
+            V3<R> att, nxt_d;
             bool done;
-            if (scatter(sc, tr.material_record(best.idx), ray, hit, dr, att, nxt)) {
+            /* the scattered ray (material.rs:81, 111, 151): from the hit point, at the incoming ray's time - origin and time are
+             * settled here, for every lane that scatters (a path that ends in the scatter has no use for its ray any more), so that
+             * only the direction travels through the material branches */
+            const V3<R> in_d = ray.d;
+            ray.o = hit.p;
+            if (scatter(sc, tr.material_record(best.idx), in_d, hit, dr, att, nxt_d)) {
                 if constexpr (REF_ORDER) {
                     const size_t o = (size_t)(bounce - 1u) * 3u * rp.att_lanes + att_lane;
                     att_stack[o] = att.x;
@@ -2154,7 +2157,7 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
                 } else {
                     thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
                 }
-                ray = nxt;
+                ray.d = nxt_d;
                 --depth_left;
                 done = depth_left == 0; /* color(.., 0) = black */
             } else {
