@@ -1552,12 +1552,19 @@ template <bool RES> struct TracerF32 {
     /* by value: the record may come from the LDS copy or from HBM/L2 (two address spaces) */
     __device__ inline DevMaterial<float> material_record(uint32_t idx) const {
         const uint32_t m = material(idx);
+        /* one generic pointer for both sources: the fields are fetched with flat_load, through the texture path also when the
+         * record sits in LDS - which suits THIS tracer, whose broad phase keeps the LDS pipe busy with record broadcasts (with
+         * ds_read here the all-VALU bench frame is 2.3 % slower, the textured 4K frame 0.8 %) */
         if (sc.n_materials <= MIRT_F32_LDS_MATS) return L.mats[m];
         return sc.mats[m];
     }
 };
 
-template <bool RES, class LDS = MxLds> struct TracerF32Mx {
+/* ML: the scene's material records sit in the block's LDS copy - a compile-time switch of the matrix-pipe tracers, one kernel body
+ * per value (picked by a block-uniform branch in the kernel).  Written as `fits ? L.mats[m] : sc.mats[m]` (above) the two sources
+ * become one generic pointer and every field is fetched with a flat_load; with the address space known the resident records
+ * come through ds_read: bench frame K2 -1.4 %. */
+template <bool RES, class LDS, bool ML> struct TracerF32Mx {
     typedef float Real;
     static constexpr bool RESUMABLE = false;
     const DevScene<float>& sc;
@@ -1582,13 +1589,13 @@ template <bool RES, class LDS = MxLds> struct TracerF32Mx {
     /* by value: the record may come from the LDS copy or from HBM/L2 (two address spaces) */
     __device__ inline DevMaterial<float> material_record(uint32_t idx) const {
         const uint32_t m = material(idx);
-        if (sc.n_materials <= LDS::N_MATS) return L.mats[m];
-        return sc.mats[m];
+        if constexpr (ML) return L.mats[m];
+        else return sc.mats[m];
     }
 };
 
 /* scenes beyond the LDS: the block's waves in step over an LDS ring of operand chunks (trace_mx_ring) */
-template <class LDS> struct TracerF32MxRing {
+template <class LDS, bool ML> struct TracerF32MxRing {
     typedef float Real;
     static constexpr bool RESUMABLE = false;
     static constexpr bool LOCKSTEP = true; /* closest() holds block barriers: every wave of the block calls it the same number of times */
@@ -1603,8 +1610,8 @@ template <class LDS> struct TracerF32MxRing {
     __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }
     __device__ inline DevMaterial<float> material_record(uint32_t idx) const {
         const uint32_t m = material(idx);
-        if (sc.n_materials <= LDS::N_MATS) return L.mats[m];
-        return sc.mats[m];
+        if constexpr (ML) return L.mats[m];
+        else return sc.mats[m];
     }
 };
 
@@ -1860,10 +1867,10 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK) void primary_hits_kernel_f32_mx(Dev
     const bool res = L.fill(sc);
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     if (res) {
-        TracerF32Mx<true> tr{sc, L, w};
+        TracerF32Mx<true, MxLds, false> tr{sc, L, w};
         primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_F32_WAVES + w, lane, out_id, out_t);
     } else {
-        TracerF32Mx<false> tr{sc, L, w};
+        TracerF32Mx<false, MxLds, false> tr{sc, L, w};
         primary_hits_body(tr, sc, cam, part, blockIdx.x * MIRT_F32_WAVES + w, lane, out_id, out_t);
     }
 }
@@ -2324,8 +2331,13 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
     const bool res = L.fill(sc); /* ends with the block barrier */
     if (res != RES) return;      /* never: the host launches <.., true> exactly for the scenes fill() makes resident */
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    TracerF32Mx<RES, LDS> tr{sc, L, w};
-    render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
+    if (sc.n_materials <= LDS::N_MATS) {
+        TracerF32Mx<RES, LDS, true> tr{sc, L, w};
+        render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
+    } else {
+        TracerF32Mx<RES, LDS, false> tr{sc, L, w};
+        render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
+    }
 }
 
 /* the same for scenes of more than MIRT_LDS_RECORDS sorted slots: operands through the block-wide LDS ring */
@@ -2336,8 +2348,13 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
     stage_params(P, cam, part, rp);
     (void)L.fill(sc); /* materials only (the scene is not resident); ends with the block barrier */
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    TracerF32MxRing<MxLds> tr{sc, L, w};
-    render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
+    if (sc.n_materials <= MxLds::N_MATS) {
+        TracerF32MxRing<MxLds, true> tr{sc, L, w};
+        render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
+    } else {
+        TracerF32MxRing<MxLds, false> tr{sc, L, w};
+        render_body(tr, sc, P->cam, P->part, P->rp, partial, stats, lane);
+    }
 }
 
 /* ---- K2b (+K3): add the chunks of a pixel in chunk order, scale by 1/spp (camera.rs:246), gamma + quantise

@@ -219,6 +219,30 @@ def test_render_is_bit_identical_on_both_broad_phases(name):
     assert st_a["narrow_tests"] <= 1.1 * st_b["narrow_tests"] + 64
 
 
+@pytest.mark.parametrize("n,n_mats", [(300, 6), (300, 300), (600, 6), (600, 600)])
+def test_material_records_from_lds_and_from_hbm(n, n_mats):
+    """The matrix-pipe kernels have one body for material records resident in LDS and one for records in HBM / L2, picked per
+    launch by the number of materials (512 fit the layout for scenes of up to 512 sorted slots, 155 that for up to 1024):
+    few shared materials and one material per sphere, either side of the layout boundary - every frame equal to the
+    vector-ALU kernel's, which fetches its records another way."""
+    rng = np.random.Generator(np.random.Philox(n + n_mats))
+    mats = []
+    for k in range(n_mats):
+        u = rng.random(5)
+        mats.append(Lambertian.new(tuple(0.2 + 0.8 * u[:3]), 0.9) if k % 3 == 0 else Metal.new(tuple(0.5 + 0.5 * u[:3]), float(0.4 * u[3])) if k % 3 == 1 else Dielectric.new(1.3 + 0.4 * float(u[4])))
+    sc = Scene()
+    c = rng.random((n, 3))
+    for i in range(n):
+        sc.add(Sphere.new_static(0.15 + 0.2 * float(rng.random()), (-8.0 + 16.0 * c[i, 0], 0.2 + 3.0 * c[i, 1], -8.0 + 16.0 * c[i, 2]), mats[i % n_mats]))
+    sc.build_bvh()
+    cam = Camera.build((13.0, 4.0, 3.0), (0.0, 1.0, 0.0), None, 160, 16.0 / 9.0, 6, 0.5, 10.0, 0.0, 20)
+    assert cam.closest_hit_kind(sc, precision=abi.F32) == "matrix"
+    a, a8 = cam.render_arrays(sc, precision=abi.F32, seed=11)
+    b, b8 = cam.render_arrays(sc, precision=abi.F32, seed=11, accel="valu")
+    assert np.array_equal(bits(a), bits(b)) and np.array_equal(a8, b8)
+    assert len(np.unique(a8.reshape(-1, 3), axis=0)) > 100  # a picture, not a constant
+
+
 def test_tiny_scenes_default_to_the_vector_alu(monkeypatch):
     from raytracer_amd import api
 
