@@ -348,7 +348,13 @@ __device__ inline void trace(const DevScene<R>& sc, WaveLds<R>& lds, uint32_t la
  *     discriminant can be >= 0 only if the real line passes within r^2 + 32 eps (|C-O|^2 + r^2) of the centre,
  *     and the evaluation above is off by at most 40 eps ((|M|+|O|)^2 + rho^2); 160 eps (|M|^2 + rho^2) on the
  *     sphere side plus 160 eps |O|^2 on the ray side covers both (eps = 2^-24).  A diagnostic build
- *     (-DMIRT_VERIFY_BROAD) re-tests every pair exactly and counts misses: 0 on every workload in bench.py. */
+ *     (-DMIRT_VERIFY_BROAD) re-tests every pair exactly and counts misses: 0 on every workload in bench.py.
+ *   - scenes of MIRT_CONS_SPARSE_FROM sorted slots and more (the streaming loop): a group of sixteen holds a candidate for some
+ *     lane of the wave only now and then, so the loop keeps the sixteen values, takes their maximum three at a time and collects
+ *     signs only in a group whose maximum says so; and with one comparison per group, k2 stays out of the per-record sum:
+ *         q + k2 = h*h + 2 O.M - w  >=  k2        7 instructions per pair, the comparison itself is exact
+ *     - the same real quantity with one rounding fewer, and the partial sums no longer carry |O|^2, so the evaluation error is
+ *     at most the one derived above (10 000 spheres at 4K: 338 -> 298 ms, 0.67 -> 0.76 of the FP32 peak; verify build 0 misses). */
 #define MIRT_RAY_SHRINK 0.99999f /* <= 1 - 160 * 2^-24 */
 /* The broad phases only FILTER (their survivors go through the exact test), so the ray-side constants need not be correctly
  * rounded: v_rsq_f32 / v_sqrt_f32 (1 ulp) instead of sqrtf + division (~25 VALU instructions per ray and segment).  The
@@ -415,6 +421,9 @@ template <class LDS> struct GeomLdsT {
 };
 typedef GeomLdsT<F32Lds> GeomLds;
 
+#ifndef MIRT_CONS_SPARSE_FROM
+#define MIRT_CONS_SPARSE_FROM 4096u /* sorted slots from which the streaming vector-ALU loop takes the maximum of a group's q before it collects signs */
+#endif
 template <bool RES>
 __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t w, uint32_t lane, bool active, const RayT<float>& ray, float tmin,
                                   Closest<float>& best, uint32_t& narrow_count, PhaseTimer& pt) {
@@ -431,6 +440,7 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
     const float nk2 = -k2;
     const uint32_t ngroups = (sc.n + MIRT_CGROUP - 1) / MIRT_CGROUP; /* the record array is padded to whole tiles */
     uint32_t(*ent)[MIRT_WAVE] = L.ent[w];
+    const bool sparse = !RES && sc.n >= MIRT_CONS_SPARSE_FROM; /* see the group loop */
 
 /* q for one record: 1 sub + 3 fma (e chain) + 3 fma (h chain) + 1 fma = 8 VALU.  q is never -0 (h*h >= +0), so its
  * sign bit is clear exactly for q >= +0 and for positive NaNs (kept: the exact test sorts them out). */
@@ -471,6 +481,43 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
             for (; g < gend && !flush; ++g) {
                 const float4* p = tp + (g * MIRT_CGROUP - tile * MIRT_TILE);
                 uint32_t acc = g - gbase;
+                if (sparse) {
+                    /* Large scenes: a group of 16 records holds a candidate for SOME lane of the wave only now and then (10 000
+                     * spheres: one group in six), and collecting a sign costs 3.4 issue cycles against the 2.2 of the
+                     * instructions that compute q.  So the sixteen values are kept, their maximum is taken three at a time (8
+                     * instructions instead of 16), and only a group in which some lane's maximum reaches the threshold collects its
+                     * signs; a group without one writes nothing, which is what an all-ones word amounts to.  With one comparison per
+                     * group instead of a sign per record the ray's k2 can stay out of the sum: q + k2 = h^2 + 2 O.M - w >= k2, one
+                     * rounding less than q >= 0 (the margins cover either order of the same few roundings; the verify build re-tests
+                     * every pair).  A NaN is skipped by the maximum and fails the comparison: such a sphere would have been a
+                     * candidate only for the exact test to reject it. */
+                    float q[MIRT_CGROUP]; /* q + k2: the ray's k2 is left out of the sum (7 instructions per record) and compared with once per group */
+#define MIRT_CONS_QK(s) __builtin_fmaf(MIRT_CONS_H(s), MIRT_CONS_H(s), __builtin_fmaf(O2.z, s.z, __builtin_fmaf(O2.y, s.y, __builtin_fmaf(O2.x, s.x, -s.w))))
+                    {
+                        const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3], s4 = p[4], s5 = p[5], s6 = p[6], s7 = p[7];
+                        q[0] = MIRT_CONS_QK(s0); q[1] = MIRT_CONS_QK(s1); q[2] = MIRT_CONS_QK(s2); q[3] = MIRT_CONS_QK(s3);
+                        q[4] = MIRT_CONS_QK(s4); q[5] = MIRT_CONS_QK(s5); q[6] = MIRT_CONS_QK(s6); q[7] = MIRT_CONS_QK(s7);
+                    }
+                    {
+                        const float4 s0 = p[8], s1 = p[9], s2 = p[10], s3 = p[11], s4 = p[12], s5 = p[13], s6 = p[14], s7 = p[15];
+                        q[8] = MIRT_CONS_QK(s0); q[9] = MIRT_CONS_QK(s1); q[10] = MIRT_CONS_QK(s2); q[11] = MIRT_CONS_QK(s3);
+                        q[12] = MIRT_CONS_QK(s4); q[13] = MIRT_CONS_QK(s5); q[14] = MIRT_CONS_QK(s6); q[15] = MIRT_CONS_QK(s7);
+                    }
+#undef MIRT_CONS_QK
+                    float m = __builtin_fmaxf(q[0], q[1]);
+#pragma unroll
+                    for (int r = 2; r < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, q[r]), q[r + 1]); /* v_max3_f32 */
+                    if (__ballot(m >= k2) == 0ull) { /* k2 = +inf for a lane without a ray */
+#ifdef MIRT_VERIFY_BROAD
+                        acc = (acc << 16) | 0xFFFFu;
+#else
+                        continue;
+#endif
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(q[r] - k2), 31); /* the difference's sign is exact */
+                    }
+                } else {
                 {
                     const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3], s4 = p[4], s5 = p[5], s6 = p[6], s7 = p[7];
                     MIRT_CONS_PUSH(s0); MIRT_CONS_PUSH(s1); MIRT_CONS_PUSH(s2); MIRT_CONS_PUSH(s3);
@@ -480,6 +527,7 @@ __device__ inline void trace_cons(const DevScene<float>& sc, F32Lds& L, uint32_t
                     const float4 s0 = p[8], s1 = p[9], s2 = p[10], s3 = p[11], s4 = p[12], s5 = p[13], s6 = p[14], s7 = p[15];
                     MIRT_CONS_PUSH(s0); MIRT_CONS_PUSH(s1); MIRT_CONS_PUSH(s2); MIRT_CONS_PUSH(s3);
                     MIRT_CONS_PUSH(s4); MIRT_CONS_PUSH(s5); MIRT_CONS_PUSH(s6); MIRT_CONS_PUSH(s7);
+                }
                 }
 #ifdef MIRT_VERIFY_BROAD
                 for (uint32_t k_ = 0; k_ < MIRT_CGROUP; ++k_) { /* exact discriminant >= 0 must imply the candidate bit */

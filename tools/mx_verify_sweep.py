@@ -11,6 +11,7 @@ from raytracer_amd.api import Camera, Dielectric, Lambertian, Metal, Scene, Sphe
 
 api.DEFAULT_FLAGS = abi.FLAG_MX_SMALL  # matrix pipe also below its size threshold
 PREC = abi.F64 if os.environ.get("MIRT_SWEEP_PRECISION") == "64" else abi.F32  # the f64 kernels use the same filter on balls around the f64 spheres
+ACCEL = os.environ.get("MIRT_SWEEP_ACCEL", "brute")  # "valu": the vector-ALU broad phase (MIRT_SWEEP_NMIN >= 4096: its sparse group test)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 mats = [Lambertian.new((0.6, 0.6, 0.6), 1.0), Metal.new((0.9, 0.9, 0.9), None), Metal.new((0.8, 0.8, 0.8), 0.2), Dielectric.new(1.5)]
 n_matrix = 0
@@ -43,6 +44,6 @@ for case in range(40):
     kind = cam.closest_hit_kind(sc, precision=PREC)
     n_matrix += kind in ("matrix", "f64-matrix")
     print(f"case {case}: n={n} scale=2^{int(np.log2(scale))} ext={ext:.1f} big={big} kind={kind}", flush=True)
-    cam.render_arrays(sc, precision=PREC, seed=case)
-    cam.primary_hits(sc, precision=PREC)
+    cam.render_arrays(sc, precision=PREC, seed=case, accel=ACCEL)
+    cam.primary_hits(sc, precision=PREC, accel=ACCEL)
 print("cases on the matrix pipe:", n_matrix)
