@@ -71,14 +71,21 @@ def test_larger_scenes_stream_their_operands(oracle, n):
     assert len(np.unique(ids)) > 100
 
 
-def test_streaming_render_is_bit_identical_on_both_broad_phases():
-    sc, cam = presets.stress_scene(3000, seed=5), presets.stress_camera(96, 4, 12)
+@pytest.mark.parametrize("n", [3000, 4000, 4200, 7000])
+def test_streaming_render_is_bit_identical_on_both_broad_phases(n, oracle):
+    """Either side of the size (4 096 sorted slots) from which the vector-ALU streaming loop takes a group's maximum before it
+    collects signs and compares with the ray's k2 once per group: matrix pipe, vector ALU and the f32 oracle, frame and map."""
+    sc, cam = presets.stress_scene(n, seed=5), presets.stress_camera(96, 4, 12)
     assert cam.closest_hit_kind(sc, precision=abi.F32) == "matrix"
     a, a8 = cam.render_arrays(sc, precision=abi.F32, seed=4)
     seg = cam.last_stats["segments"]
     b, b8 = cam.render_arrays(sc, precision=abi.F32, seed=4, accel="valu")
     assert cam.last_stats["segments"] == seg
     assert np.array_equal(bits(a), bits(b)) and np.array_equal(a8, b8)
+    cam0 = presets.stress_camera(96, 0, 12)
+    ids, t = cam0.primary_hits(sc, precision=abi.F32, accel="valu")
+    o_ids, o_t = oracle.primary_hits(sc.flat, cam0.pod, abi.F32)
+    assert np.array_equal(ids, o_ids) and np.array_equal(bits(t), bits(o_t))
 
 
 def test_ring_kernel_bands_passes_and_tiny_frames():
