@@ -670,9 +670,19 @@ template <uint32_t RECORDS, uint32_t MATS, uint32_t ENT_WORDS = 12, uint32_t PAI
                 mat[i] = (uint16_t)sc.material[i];
                 if (PAIRS) oid[i] = (uint16_t)sc.orig_id[i]; /* < RECORDS real spheres: the ids fit (a dummy's 0xFFFF never wins) */
             }
+        } else if (top_tiles_resident(sc)) {
+            /* a scene beyond the LDS whose waves stream their own tiles (mx_cull 3): the operand area is free, and the TOP tiles -
+             * one per 32 tiles, all of them tested by every wave in every segment - fit it */
+            const uint32_t ntiles = (sc.n + 31) / 32, ntop = (ntiles + 31u) / 32u;
+            for (uint32_t i = threadIdx.x; i < ntop * 128u; i += blockDim.x) SM[i] = sc.SM[ntiles * 128u + i];
         }
         __syncthreads();
         return res;
+    }
+    /* wave-uniform: the top tiles of this (streamed) scene sit in SM[0 .. ntop * 128) */
+    __device__ static inline bool top_tiles_resident(const DevScene<float>& sc) {
+        const uint32_t ntiles = (sc.n + 31) / 32, ntop = (ntiles + 31u) / 32u;
+        return sc.n > RECORDS && sc.mx_cull == 3u && ntop * 128u <= RECORDS * 4u + 128u;
     }
 };
 #define MIRT_MX_SMALL_RECORDS 512u
@@ -1031,6 +1041,17 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
     };
     if (streamed) {
         const uint32_t ntop = (ntiles + 31u) / 32u; /* <= 128 (mx_cull_mode: MIRT_MX_CULL_TILES) */
+        bool top_in_lds = false;
+        if constexpr (sizeof(R) == 4 && !RES) top_in_lds = LDS::top_tiles_resident(sc); /* copied by fill(): the f32 render kernel's operand area */
+        if (top_in_lds) {
+            const mirt_h8* TSM = (const mirt_h8*)L.SM;
+            for (uint32_t j = 0; j < ntop; ++j) {
+                const uint32_t wj = mx_need_word(TSM[j * 128 + lane], TSM[j * 128 + 64 + lane], bx0, bx1, by0, by1);
+                needv0 = lane == j ? wj : needv0;
+                needv1 = lane + 64u == j ? wj : needv1;
+                ++tiles_done;
+            }
+        } else {
         mirt_h8 p0 = SM[ntiles * 128 + lane], p1 = SM[ntiles * 128 + 64 + lane];
         for (uint32_t j = 0; j < ntop; ++j) {
             const mirt_h8 a0 = p0, a1 = p1;
@@ -1039,6 +1060,7 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
             needv0 = lane == j ? wj : needv0;
             needv1 = lane + 64u == j ? wj : needv1;
             ++tiles_done;
+        }
         }
 #ifdef MIRT_VERIFY_BROAD
         for (uint32_t s_ = 0; s_ < ntiles; ++s_)
