@@ -2433,13 +2433,19 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
  *      own pixel's chunks would touch a different cache line than its neighbours with every load.  Instead the wave
  *      copies MIRT_RESOLVE_TC chunks of its 64 pixels at a time into LDS with consecutive lanes on consecutive words,
  *      and each lane adds its pixel's chunks from there, in chunk order as before (bit-identical sums). */
+/* chunks of a pixel per stage, a template parameter picked by the host: 16 where a pass holds that many (bench frame, 32 chunks:
+ * 0.234 -> 0.208 ms against 8; 32 at two waves per block: 0.314), 8 otherwise (the 4K frames have 8 chunks: with the larger tile
+ * half empty and half as many blocks per CU their resolve went from 0.175 to 0.236 ms) */
+#define MIRT_RESOLVE_TC_WIDE 16u
 #define MIRT_RESOLVE_TC 8u
+#ifndef MIRT_RESOLVE_WAVES
 #define MIRT_RESOLVE_WAVES 4u
-template <class R>
+#endif
+template <class R, uint32_t TC_>
 __global__ __launch_bounds__(MIRT_RESOLVE_WAVES * MIRT_WAVE) void resolve_kernel(const R* __restrict__ partial, DevCamera<R> cam, DevPart part, RenderParams rp,
                                                                                    uint32_t n_pixels, R* __restrict__ out_lin, uint8_t* __restrict__ out_rgb8,
                                                                                    DevStats* __restrict__ stats, R* accum) {
-    constexpr uint32_t TC = MIRT_RESOLVE_TC, STRIDE = TC * 3u + 1u; /* odd stride: the lanes' rows start in different banks */
+    constexpr uint32_t TC = TC_, STRIDE = TC * 3u + 1u; /* odd stride: the lanes' rows start in different banks */
     __shared__ R tile_all[MIRT_RESOLVE_WAVES][MIRT_WAVE * STRIDE];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     R* tile = tile_all[w];
@@ -2464,16 +2470,22 @@ __global__ __launch_bounds__(MIRT_RESOLVE_WAVES * MIRT_WAVE) void resolve_kernel
         for (uint32_t c1 = 0; c1 < n; c1 += TC) {
             const uint32_t m = n - c1 < TC ? n - c1 : TC, m3 = m * 3u, count = nvalid * m3;
             __syncthreads(); /* the adds of the previous group are done with the tile */
-            if (sizeof(R) == 4 && m == TC && rp.g_shift >= 2) {
-                /* full groups of f32 sums: 16-byte loads (a pixel's TC chunks are 6 aligned float4: slot numbers are multiples
-                 * of G >= 4 here, c1 of TC, and the workspace is a hipMalloc block) */
-                for (uint32_t e = lane; e < nvalid * (TC * 3u / 4u); e += MIRT_WAVE) {
-                    const uint32_t j = e / (TC * 3u / 4u), r = (e - j * (TC * 3u / 4u)) * 4u;
+            /* groups of 16, 8 or 4 f32 sums: 16-byte loads (M chunks of a pixel are 3 M / 4 aligned float4: slot numbers are
+             * multiples of G >= 4 here, c1 of TC, and the workspace is a hipMalloc block) */
+            auto copy16 = [&](auto mc) {
+                constexpr uint32_t Q4 = decltype(mc)::value * 3u / 4u; /* float4 per pixel */
+                for (uint32_t e = lane; e < nvalid * Q4; e += MIRT_WAVE) {
+                    const uint32_t j = e / Q4, r = (e - j * Q4) * 4u;
                     const float4 v = *reinterpret_cast<const float4*>(p + ((size_t)j * G + c1) * 3 + r);
                     R* d = tile + j * STRIDE + r;
                     d[0] = (R)v.x; d[1] = (R)v.y; d[2] = (R)v.z; d[3] = (R)v.w;
                 }
-            } else {
+            };
+            const bool wide = sizeof(R) == 4 && rp.g_shift >= 2;
+            if (wide && TC >= 16u && m == 16u) copy16(std::integral_constant<uint32_t, 16u>{});
+            else if (wide && m == 8u) copy16(std::integral_constant<uint32_t, 8u>{});
+            else if (wide && m == 4u) copy16(std::integral_constant<uint32_t, 4u>{});
+            else {
                 for (uint32_t e = lane; e < count; e += MIRT_WAVE) {
                     const uint32_t j = m == TC ? e / (TC * 3u) : e / m3, r = e - j * m3;
                     tile[j * STRIDE + r] = p[((size_t)j * G + c1) * 3 + r];
