@@ -1643,9 +1643,12 @@ template <bool RES, class LDS, bool ML> struct TracerF32Mx {
     uint32_t tiles = 0; /* tiles of 32 spheres this wave ran through the matrix pipe (wave-uniform): what the tile cull left */
     __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
         const unsigned long long live = __ballot(active);
-        if ((uint32_t)__popcll(live) <= MIRT_FEW_LANES) {
-            if (RES) trace_few(sc, GeomLdsT<LDS>{L}, lane, live, ray, tmin, best, nc);
-            else trace_few(sc, GeomGlobal<float>{sc}, lane, live, ray, tmin, best, nc);
+        /* resident scenes only: trace_few runs n / 64 rounds of the exact test per live ray - 16 rounds from LDS at most - but
+         * beyond the LDS every round is a dependent trip to L2 (10 000 spheres: 157 per ray, ~45 us per ray and bounce: the one
+         * wave with a path inside a glass ball outlived all others by 6 ms of the 38 ms stress frame), while the culled tile
+         * loop below costs such a wave its top tiles and the handful of tiles its few rays can touch */
+        if (RES && (uint32_t)__popcll(live) <= MIRT_FEW_LANES) {
+            trace_few(sc, GeomLdsT<LDS>{L}, lane, live, ray, tmin, best, nc);
             pt.stamp(PH_NARROW);
         } else {
             trace_mx<float, LDS, RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt, tiles);
