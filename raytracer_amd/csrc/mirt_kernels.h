@@ -1330,7 +1330,7 @@ __device__ inline void trace_mx_ring(const DevScene<float>& sc, LDS& L, uint32_t
  * all the broad phases ever filter for.  ~8 rounds of one exact test per ray for the bench scene instead of 16 tiles of
  * matrix work: the tail of an 8-GPU band shrinks from ~1 ms to ~0.2 ms. */
 #ifndef MIRT_FEW_LANES
-#define MIRT_FEW_LANES 4u
+#define MIRT_FEW_LANES 2u /* a wave alone on its SIMD (tools/lone_wave_probe.py): 0.9 us + 1.55 us per ray this way, ~5.1 us through the tile loop whatever the number of rays; 4: a wave of 4 rays 7.1 us per iteration instead of 5.1 */
 #endif
 template <class R, class G>
 __device__ inline void trace_few(const DevScene<R>& sc, const G& geo, uint32_t lane, unsigned long long live, const RayT<R>& ray, R tmin, Closest<R>& best,
@@ -1360,6 +1360,77 @@ __device__ inline void trace_few(const DevScene<R>& sc, const G& geo, uint32_t l
             best.t = __uint_as_float(kt);
             best.idx = kidx;
             narrow_count += (sc.n + MIRT_WAVE - 1) / MIRT_WAVE; /* charged to the ray's lane: exact tests per lane and ray */
+        }
+    }
+}
+
+/* minimum of a 64-bit key over the wave (every lane gets it): the DPP steps of wave_scan_incl with min for +; a lane a step
+ * does not reach keeps its own value (old = the value itself) */
+#define MIRT_MIN64_STEP(ctrl, rm)                                                                          \
+    {                                                                                                      \
+        const uint32_t ohi_ = (uint32_t)__builtin_amdgcn_update_dpp((int)hi_, (int)hi_, ctrl, rm, 0xF, false); \
+        const uint32_t olo_ = (uint32_t)__builtin_amdgcn_update_dpp((int)lo_, (int)lo_, ctrl, rm, 0xF, false); \
+        const bool take_ = ohi_ < hi_ || (ohi_ == hi_ && olo_ < lo_);                                          \
+        hi_ = take_ ? ohi_ : hi_;                                                                          \
+        lo_ = take_ ? olo_ : lo_;                                                                          \
+    }
+__device__ inline unsigned long long wave_min_u64(unsigned long long k) {
+    uint32_t lo_ = (uint32_t)k, hi_ = (uint32_t)(k >> 32);
+    MIRT_MIN64_STEP(0x111, 0xF) MIRT_MIN64_STEP(0x112, 0xF) MIRT_MIN64_STEP(0x114, 0xF) MIRT_MIN64_STEP(0x118, 0xF)
+    MIRT_MIN64_STEP(0x142, 0xA) MIRT_MIN64_STEP(0x143, 0xC)
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi_, 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo_, 63);
+}
+/* trace_few for the LDS layouts that hold the hit ids (the pair ring's: scenes of <= MIRT_MX_SMALL_RECORDS slots).  A wave in
+ * this state runs alone on its SIMD - nothing hides a latency - and trace_few's rounds are one dependent chain each: load,
+ * discriminant, and for whichever lane's sphere the line meets the square root and the divisions, round after round (1.75 us per
+ * ray, tools/lone_wave_probe.py).  Here the discriminants of all of a lane's spheres (<= 8) come first, independent of each
+ * other, then only the spheres that can contribute a root go through pair_key - the exact test of the balanced narrow phase, whose
+ * 64-bit (t, hit id, slot) keys order like narrow_test's closest hit (see there) - and the wave takes the minimum. */
+template <class LDS>
+__device__ inline void trace_few_keys(const DevScene<float>& sc, const LDS& L, uint32_t lane, unsigned long long live, const RayT<float>& ray, float tmin,
+                                      Closest<float>& best, uint32_t& narrow_count) {
+    static_assert(LDS::PAIR_CAP > 0, "needs L.oid");
+    const GeomLdsT<LDS> geo{L};
+    best.t = INFINITY;
+    best.idx = 0xFFFFFFFFu;
+    while (live != 0ull) {
+        const int Lr = __ffsll((long long)live) - 1;
+        live &= live - 1ull;
+        auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), Lr)); };
+        const RayT<float> r = {{bc(ray.o.x), bc(ray.o.y), bc(ray.o.z)}, {bc(ray.d.x), bc(ray.d.y), bc(ray.d.z)}, bc(ray.tm)};
+        const RayA<float> a = ray_a(r.d);
+        uint32_t m = 0; /* bit k: sphere lane + 64 k passes the test pair_key starts with (same operations on the same values) */
+#pragma unroll 1
+        for (uint32_t k0 = 0; k0 < MIRT_MX_SMALL_RECORDS / MIRT_WAVE; k0 += 4) /* four at a time: eight would spill */
+#pragma unroll
+        for (uint32_t k = k0; k < k0 + 4; ++k) {
+            const uint32_t i = lane + k * MIRT_WAVE;
+            const bool in = i < sc.n;
+            const uint32_t ic = in ? i : 0u;
+            const float4 sa = geo.a(ic), sb = geo.b(ic);
+            V3<float> C = {sa.x, sa.y, sa.z};
+            const V3<float> Cm = center_at(C, V3<float>{sb.x, sb.y, sb.z}, r.tm);
+            if (ic >= sc.n_static) C = Cm;
+            float h, d;
+            disc(C - r.o, r.d, a, sa.w, h, d);
+            if (in && d >= 0.0f && !(h < -h_normal_min(h) && d <= h * h && tmin >= 0.0f)) m |= 1u << k;
+        }
+        unsigned long long key = MIRT_KEY_NONE;
+        while (__ballot(m != 0u) != 0ull) {
+            if (m != 0u) {
+                const uint32_t i = lane + ((uint32_t)__ffs((int)m) - 1u) * MIRT_WAVE;
+                m &= m - 1u;
+                const unsigned long long kk = pair_key(sc, geo, i, (uint32_t)L.oid[i], r, a, tmin);
+                key = kk < key ? kk : key;
+            }
+        }
+        key = wave_min_u64(key);
+        if ((int)lane == Lr) {
+            if (key != MIRT_KEY_NONE) {
+                best.t = __uint_as_float((uint32_t)(key >> 32));
+                best.idx = (uint32_t)key & 0xFFFFu;
+            }
+            narrow_count += (sc.n + MIRT_WAVE - 1) / MIRT_WAVE; /* as trace_few counts */
         }
     }
 }
@@ -1648,7 +1719,8 @@ template <bool RES, class LDS, bool ML> struct TracerF32Mx {
          * wave with a path inside a glass ball outlived all others by 6 ms of the 38 ms stress frame), while the culled tile
          * loop below costs such a wave its top tiles and the handful of tiles its few rays can touch */
         if (RES && (uint32_t)__popcll(live) <= MIRT_FEW_LANES) {
-            trace_few(sc, GeomLdsT<LDS>{L}, lane, live, ray, tmin, best, nc);
+            if constexpr (mx_pair_cap<LDS>::value > 0 && LDS::N_RECORDS <= MIRT_MX_SMALL_RECORDS) trace_few_keys(sc, L, lane, live, ray, tmin, best, nc);
+            else trace_few(sc, GeomLdsT<LDS>{L}, lane, live, ray, tmin, best, nc);
             pt.stamp(PH_NARROW);
         } else {
             trace_mx<float, LDS, RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt, tiles);
