@@ -1663,14 +1663,14 @@ struct TracerF64 {
     __device__ inline uint32_t material(uint32_t idx) const { return sc.material[idx]; }
     __device__ inline const DevMaterial<double>& material_record(uint32_t idx) const { return sc.mats[material(idx)]; }
 };
-template <bool RES> struct TracerF32 {
+template <bool RES, bool ONLY_TINY = false> struct TracerF32 { /* ONLY_TINY: the kernel the host launches for scenes of <= MIRT_TINY_SCENE slots - nothing but the exact tests is compiled in */
     typedef float Real;
     static constexpr bool RESUMABLE = false;
     const DevScene<float>& sc;
     F32Lds& L;
     uint32_t w;
     __device__ inline void closest(uint32_t lane, bool active, const RayT<float>& ray, float tmin, Closest<float>& best, uint32_t& nc, PhaseTimer& pt) {
-        if (RES && sc.n_live <= MIRT_TINY_SCENE) {
+        if (ONLY_TINY || (RES && sc.n_live <= MIRT_TINY_SCENE)) {
             /* a handful of spheres (the textured presets have 1-3): the exact test on each of them, no lists, no broad
              * phase - 16 bounding records per group would be mostly padding */
             best.t = INFINITY;
@@ -1683,6 +1683,8 @@ template <bool RES> struct TracerF32 {
             pt.stamp(PH_NARROW);
             return;
         }
+        /* (trace_few for the last rays of a wave, as in the matrix-pipe tracer: a lone wave's iteration 14.2 -> 2.8 us, the all-VALU
+         * bench frame 27.07 -> 27.19 ms - measured and dropped) */
         trace_cons<RES>(sc, L, w, lane, active, ray, tmin, best, nc, pt);
     }
     __device__ inline Hit<float> hit(const Closest<float>& c, const RayT<float>& ray) const {
@@ -2457,7 +2459,7 @@ __global__ __launch_bounds__(MIRT_F32_BLOCK, MIRT_F32_EU) void render_kernel_f32
     stage_params(&P, cam, part, rp);
     L.fill(sc); /* ends with the block barrier; a scene this small is always resident */
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    TracerF32<true> tr{sc, L, w};
+    TracerF32<true, true> tr{sc, L, w};
     render_body(tr, sc, P.cam, P.part, P.rp, partial, stats, lane);
 }
 
