@@ -1,1 +1,3 @@
-for v in a_base k_keys k_keys2 k_keys8; do echo "== $v"; MIRT_LIB=$PWD/variants/$v.so timeout -k 10 120 python3 tools/lone_wave_probe.py 2>&1 | sed 's/.*px = lanes/ lanes/' | cut -c1-150 || exit 1; done
+#!/bin/bash
+# tools/lone_wave_ab.sh "a b ..." : tools/lone_wave_probe.py for variants/<name>.so, one after the other on one box
+for v in $1; do echo "== $v"; MIRT_LIB=$PWD/variants/$v.so timeout -k 10 120 python3 tools/lone_wave_probe.py 2>/dev/null | sed 's/.*px = lanes/ lanes/' | cut -c1-150 || exit 1; done
