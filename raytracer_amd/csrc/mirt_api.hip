@@ -573,6 +573,9 @@ static int ws_grow(void** buf, size_t* have, size_t need, const char* what) {
     return MIRT_OK;
 }
 #define MIRT_ATT_STACK_LIMIT (8192ull << 20)
+/* launches of fewer work items per lane of the grid than this have no continuation pass (launch_render): the second launch costs
+ * ~0.1 ms (10 000 spheres at 1080p x 4 spp, 32 items per lane: 4.0 -> 4.1 ms with it; at 4K x 16 spp, 253 per lane: 35.3 -> 33.2 ms) */
+#define MIRT_CONT_ITEMS_PER_LANE 64ull
 
 /* resident blocks per CU of every render kernel, asked once per process (not per call) */
 static int occupancy_of(const void* fn, int block) {
@@ -671,8 +674,18 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
     rp.d_strip = make_fastdiv(part.strip_rows);
     rp.keep_num = 0;
     rp.att_lanes = 0;
+    rp.cont_mode = 0;
     int rc;
-    const size_t need = (size_t)rp.n_items * 3 * sizeof(R); /* one slot per queue position */
+    size_t need = (size_t)rp.n_items * 3 * sizeof(R); /* one slot per queue position */
+    /* continuation pass (render_body, T::CONTINUES: the f32 kernel for scenes beyond the LDS): room for the state of one path per
+     * lane of the grid behind the partial sums, where the launch is long enough to have a tail worth it and the room is there
+     * (the static scratch may be too small: then the launch simply runs to its end as before) */
+    bool cont = false;
+    if (sizeof(R) == 4 && bvh == 7 && cam->max_bounce_depth != 0) {
+        const uint64_t lanes = (uint64_t)s->n_cus * occupancy_of(render_fn(R(), bvh), (int)block) * block; /* the grid is at most this */
+        const size_t with = ((((size_t)rp.n_items * 3 + 63) & ~(size_t)63) + (size_t)MIRT_CONT_FIELDS * lanes) * sizeof(R);
+        if ((uint64_t)rp.n_items >= MIRT_CONT_ITEMS_PER_LANE * lanes && (!ws.fixed_base || with <= ws.fixed_cap)) { cont = true; need = with; }
+    }
     R* partial = nullptr;
     if (ws.fixed_base) {
         if (need > ws.fixed_cap)
@@ -725,6 +738,12 @@ static int launch_render(const mirt_scene* s, const SceneBuffers<R>& b, const mi
         if (bvh == 1 || bvh == 2) { /* suspend a traversal once this share (in 64ths) of the traversing lanes is all that is left (mirt_opts.bvh_keep) */
             rp.keep_num = bvh == 1 ? 32 : 16; /* measured: profiles/r01_microbench.txt */
             if (o->bvh_keep) rp.keep_num = o->bvh_keep;
+        }
+        if (cont && (uint64_t)rp.n_items >= MIRT_CONT_ITEMS_PER_LANE * grid * block) { /* (the grid is smaller than its bound only for launches too short to pass this) */
+            rp.cont_mode = 1;
+            launch_render_kernel((uint32_t)grid, block, bvh, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, rp, partial, ws.stats, att);
+            HIP_TRY(hipGetLastError());
+            rp.cont_mode = 2; /* the same grid: the slots are spread over its waves */
         }
         launch_render_kernel((uint32_t)grid, block, bvh, st, dev_scene<R>(s, b), dev_camera<R>(cam), part, rp, partial, ws.stats, att);
         HIP_TRY(hipGetLastError());

@@ -121,7 +121,7 @@ template <class R> struct GeomGlobal {
 struct DevStats { /* device-side counters, one atomic per wave at kernel end */
     unsigned long long segments, narrow, wave_iters, nan_pixels;
     unsigned int queue_head; /* next unclaimed work item of the running render launch */
-    unsigned int _pad;
+    unsigned int cont_count; /* paths handed to the continuation pass (render_body, T::CONTINUES) */
     unsigned long long mx_tiles; /* matrix-pipe kernels: (wave, tile of 32 spheres) evaluations, i.e. what the tile cull left of wave_iters x tiles */
     unsigned long long phase_cycles[6]; /* diagnostic builds only (MIRT_PHASE_TIMING) */
     unsigned long long broad_misses;    /* diagnostic builds only (MIRT_VERIFY_BROAD): must be 0 */
@@ -134,6 +134,8 @@ struct DevStats { /* device-side counters, one atomic per wave at kernel end */
     unsigned long long idle_sum;        /* sum over waves of (end of the wave - its last iteration with a full complement of work): the drain */
     unsigned long long bvh_lane_steps, bvh_wave_steps, bvh_leaf_rounds, bvh_lane_leaves; /* -DMIRT_PHASE_TIMING -DMIRT_BVH_COUNTERS */
     unsigned long long diag[48]; /* -DMIRT_PHASE_TIMING: MIRT_DIAG, [k] wave-level entries of block k, [24 + k] lanes that entered it */
+    unsigned int waves_done;     /* T::CONTINUES, first launch: waves that have ended (render_body) */
+    unsigned int _pad2;
 };
 
 /* Diagnostic build only (-DMIRT_PHASE_TIMING -DMIRT_BLOCK_COUNTS): wave-level execution counts of the divergent blocks of the segment loop
@@ -1710,6 +1712,7 @@ template <bool RES, bool ONLY_TINY = false> struct TracerF32 { /* ONLY_TINY: the
 template <bool RES, class LDS, bool ML> struct TracerF32Mx {
     typedef float Real;
     static constexpr bool RESUMABLE = false;
+    static constexpr bool CONTINUES = !RES; /* scenes beyond the LDS: the paths the last waves are left with go to a second launch (render_body) */
     const DevScene<float>& sc;
     LDS& L;
     uint32_t w;
@@ -2054,6 +2057,7 @@ struct RenderParams {
     uint32_t g_shift;    /* queue order: 2^g_shift consecutive chunks of a pixel sit next to each other (see render_body) */
     uint32_t keep_num;   /* resumable tree traversal: go on while >= keep_num/64 of the traversing lanes are still at it (0: run to the end) */
     uint32_t att_lanes;  /* f64 kernels: lanes of the grid = stride of the per-lane attenuation stacks (0 in the f32 kernels) */
+    uint32_t cont_mode;  /* tracers with T::CONTINUES: 0 = off, 1 = this launch hands the paths its last waves are left with to a second one, 2 = the second one (render_body) */
 };
 
 /* Order of the floating-point operations that build a pixel (camera.rs:242-246, 277):
@@ -2066,6 +2070,19 @@ struct RenderParams {
 /* T::LOCKSTEP, where a tracer declares it */
 template <class T, class = void> struct tracer_lockstep { static constexpr bool value = false; };
 template <class T> struct tracer_lockstep<T, decltype((void)T::LOCKSTEP)> { static constexpr bool value = T::LOCKSTEP; };
+/* T::CONTINUES, where a tracer declares it */
+template <class T, class = void> struct tracer_continues { static constexpr bool value = false; };
+template <class T> struct tracer_continues<T, decltype((void)T::CONTINUES)> { static constexpr bool value = T::CONTINUES; };
+#define MIRT_CONT_FIELDS 22u /* dwords of path state per handed-over lane */
+#ifndef MIRT_CONT_AFTER
+#define MIRT_CONT_AFTER 1u   /* iterations a wave goes on after it has nothing left to deal before it may hand its paths over */
+#endif
+#ifndef MIRT_CONT_LATE
+#define MIRT_CONT_LATE 32u   /* ... and only once all but 1 / MIRT_CONT_LATE of the grid's waves have ended (10 000-sphere 4K frame: 4 / 8 / 16 / 32 / 64: 34.9 / 34.4 / 33.9 / 33.7 / 33.6 ms, 35.2 without; 0 / 1 / 2 iterations first: 35.7 / 35.0 / 35.0) */
+#endif
+#ifndef MIRT_CONT_MIN
+#define MIRT_CONT_MIN 4u     /* ... if more than this many lanes still have one */
+#endif
 /* tr.tiles, where a tracer counts them */
 template <class T, class = void> struct tracer_tiles { static __device__ inline uint32_t get(const T&) { return 0u; } };
 template <class T> struct tracer_tiles<T, decltype((void)((T*)nullptr)->tiles)> { static __device__ inline uint32_t get(const T& t) { return t.tiles; } };
@@ -2183,6 +2200,35 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
         ray = aa ? ray_for(cam, lx, gy, dr) : primary_ray(cam, lx, gy);
         need_ray = false;
     };
+    /* ---- continuation pass (T::CONTINUES; scenes beyond the LDS) -----------------------------------------------
+     * The end of such a launch is a few waves with a full complement of long paths each (the 64 items of a tail batch are
+     * neighbouring pixels, all on one glass sphere: 100 iterations at the 16-40 us a wave of 64 rays takes, while the chip is
+     * empty - DESIGN 9.5).  A wave that has nothing left to deal and still holds more than MIRT_CONT_MIN paths after
+     * MIRT_CONT_AFTER more iterations writes their state behind the partial sums and ends; a second launch of the same kernel
+     * (cont_mode 2) spreads all such paths evenly over its waves - a handful each, at the 8 us per iteration of a wave with few
+     * rays.  A path goes on exactly where it stopped (same counters, same sums in the same order): the image is the same. */
+    [[maybe_unused]] uint32_t drain_n = 0;
+    [[maybe_unused]] R* const cont = partial + (((size_t)rp.n_items * 3u + 63u) & ~(size_t)63u);
+    [[maybe_unused]] const uint32_t cont_cap = gridDim.x * blockDim.x;
+    if constexpr (tracer_continues<T>::value) {
+        if (rp.cont_mode == 2u) {
+            const uint32_t count = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&stats->cont_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const uint32_t nw = gridDim.x * (blockDim.x / MIRT_WAVE), gw = blockIdx.x * (blockDim.x / MIRT_WAVE) + (threadIdx.x / MIRT_WAVE);
+            uint32_t per = (count + nw - 1u) / nw; /* <= 64: at most one path per lane of the first launch, and the grids are the same */
+            per = per < 1u ? 1u : per;
+            const uint32_t slot = gw * per + lane;
+            if (lane < per && slot < count && count <= cont_cap) {
+                auto ld = [&](uint32_t f) { return cont[(size_t)f * cont_cap + slot]; };
+                auto ldu = [&](uint32_t f) { return __float_as_uint(ld(f)); };
+                item = ldu(0); pixel = ldu(1); lx = ldu(2); gy = ldu(3); sample = ldu(4); s_end = ldu(5); depth_left = ldu(6);
+                bounce = ldu(7) & 0x7FFFFFFFu; need_ray = (ldu(7) >> 31) != 0u;
+                acc = {ld(8), ld(9), ld(10)}; thr = {ld(11), ld(12), ld(13)};
+                ray.o = {ld(14), ld(15), ld(16)}; ray.d = {ld(17), ld(18), ld(19)}; ray.tm = ld(20);
+                has_work = true;
+            }
+            exhausted = true; /* this launch deals nothing */
+        }
+    }
     deal();
     pt.stamp(PH_QUEUE);
     {
@@ -2198,6 +2244,31 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
 #ifdef MIRT_PHASE_TIMING
         if (exhausted) ++drain_iters;
 #endif
+        if constexpr (tracer_continues<T>::value) {
+            if (rp.cont_mode == 1u && exhausted && q_next == q_end && ++drain_n > MIRT_CONT_AFTER) {
+                const unsigned long long lv = __ballot(has_work);
+                const uint32_t nl = (uint32_t)__popcll(lv);
+                /* ... and only a wave that is LATE: all but 1 / MIRT_CONT_LATE of the grid's waves have ended (where all waves end together - a
+                 * depth limit of 1, a short launch - handing over would only move the last iteration or two into a second launch) */
+                const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&stats->waves_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (nl > MIRT_CONT_MIN && MIRT_CONT_LATE * done >= (MIRT_CONT_LATE - 1u) * (gridDim.x * (blockDim.x / MIRT_WAVE))) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&stats->cont_count, nl);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (has_work) { /* base + nl <= cont_cap: a lane hands over at most once per launch */
+                        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(lv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lv, 0u));
+                        auto st = [&](uint32_t f, R v) { cont[(size_t)f * cont_cap + slot] = v; };
+                        auto stu = [&](uint32_t f, uint32_t v) { st(f, __uint_as_float(v)); };
+                        stu(0, item); stu(1, pixel); stu(2, lx); stu(3, gy); stu(4, sample); stu(5, s_end); stu(6, depth_left);
+                        stu(7, bounce | (need_ray ? 0x80000000u : 0u));
+                        st(8, acc.x); st(9, acc.y); st(10, acc.z); st(11, thr.x); st(12, thr.y); st(13, thr.z);
+                        st(14, ray.o.x); st(15, ray.o.y); st(16, ray.o.z); st(17, ray.d.x); st(18, ray.d.y); st(19, ray.d.z); st(20, ray.tm);
+                        has_work = false;
+                        need_ray = false;
+                    }
+                }
+            }
+        }
         /* every lane's path ended inside the last scatter (a depth limit of 1 does that in every iteration): the wave's reserved
          * batch and the queue may still hold items - deal before deciding that the wave is done.  The lanes start their samples
          * after the coming (for them empty) segment like any lane that ends in a scatter. */
@@ -2353,6 +2424,12 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
         atomicAdd(&stats->n_waves, 1ull);
     }
 #endif
+    if constexpr (tracer_continues<T>::value) {
+        if (rp.cont_mode == 1u && lane == 0) atomicAdd(&stats->waves_done, 1u);
+        /* a wave of the second launch that was handed nothing has nothing to add - and 4 096 waves ending at the same moment
+         * would queue up on the counters below for 150 us */
+        if (n_iter == 0u) return;
+    }
     uint32_t s1 = wave_sum_u(n_seg), s2 = wave_sum_u(n_narrow);
     if (lane == 0) {
         atomicAdd(&stats->segments, (unsigned long long)s1);

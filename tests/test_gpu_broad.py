@@ -88,6 +88,39 @@ def test_streaming_render_is_bit_identical_on_both_broad_phases(n, oracle):
     assert np.array_equal(ids, o_ids) and np.array_equal(bits(t), bits(o_t))
 
 
+def test_continuation_pass_frame_bands_and_passes_are_bit_identical():
+    """Scenes beyond the LDS, launches of >= 64 items per lane of the chip: the waves that are left with paths when the queue is
+    dry hand them to a second launch of the kernel (render_body, T::CONTINUES).  A frame large enough for that - whole, as two
+    bands, and as two progressive passes - is the vector-ALU kernel's frame bit for bit, with the same number of segments."""
+    import ctypes as C
+
+    sc = presets.stress_scene(1500, seed=12)
+    cam = presets.stress_camera(2560, 16, 50)  # 3.7 M pixels x 16 one-sample items = 225 per lane; a band or a pass: 112
+    assert cam.closest_hit_kind(sc, precision=abi.F32) == "matrix"
+    a, a8 = cam.render_arrays(sc, precision=abi.F32, seed=9)
+    seg = cam.last_stats["segments"]
+    b, b8 = cam.render_arrays(sc, precision=abi.F32, seed=9, accel="valu")
+    assert cam.last_stats["segments"] == seg
+    assert np.array_equal(bits(a), bits(b)) and np.array_equal(a8, b8)
+    lib, ds = abi.load(), sc.device_scene(0)
+    acc = np.zeros_like(a)
+    segs = 0
+    for r in range(2):
+        part = np.zeros_like(a)
+        o = cam.opts(precision=abi.F32, seed=9, strip_rows=8, part_index=r, part_count=2)
+        st = abi.MirtStats()
+        abi.check(lib.mirt_render(ds.handle, C.byref(cam.pod), C.byref(o), part.ctypes.data, None, C.byref(st)))
+        acc += part
+        segs += st.segments
+    assert segs == seg and np.array_equal(bits(acc), bits(a))
+    g = cam.pass_granularity(precision=abi.F32)
+    assert g <= 2
+    accum = np.full(a.shape, np.nan, np.float32)
+    for first, count in ((0, 8), (8, 8)):
+        lin, _ = cam.render_pass(sc, first, count, accum, precision=abi.F32, seed=9)
+    assert np.array_equal(bits(lin), bits(a))
+
+
 def test_ring_kernel_bands_passes_and_tiny_frames():
     """Scenes beyond the LDS run render_kernel_f32_mx_ring, whose waves move through the tiles in step behind block barriers
     and leave the loop together.  Bands of a partition, progressive passes, a frame with fewer items than one block has
