@@ -2396,7 +2396,7 @@ __device__ inline void render_body(T& tr, const DevScene<typename T::Real>& sc, 
         pt.stamp(PH_RAYGEN);
     }
 #ifdef MIRT_PHASE_TIMING
-    if (lane == 0) {
+    if (lane == 0 && rp.cont_mode != 2u) { /* (the continuation launch is left out of the diagnostic: its waves have no queue phase) */
         const unsigned long long wave_t1 = __builtin_amdgcn_s_memrealtime(); /* before the atomics below: 4096 waves ending together queue up on them */
         const unsigned long long wave_c1 = __builtin_amdgcn_s_memtime();
         for (int i = 0; i < 6; ++i) atomicAdd(&stats->phase_cycles[i], pt.acc[i]);
