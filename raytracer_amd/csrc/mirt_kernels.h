@@ -1097,6 +1097,9 @@ __device__ inline void trace_mx(const DevScene<R>& sc, LDS& L, uint32_t w, uint3
             uint32_t from_b = (row & 4u) ? 0xFFFFFFFFu : 0u, in_sub1 = sub ? 0xFFFFFFFFu : 0u;
             asm volatile("" : "+v"(from_b), "+v"(in_sub1)); /* masks, not conditions: the compiler turns `mask & x` back into a move and a select otherwise */
             uint32_t in_pass = 0; /* tiles of this pass so far (wave-uniform): cnt <= in_pass, so the list cannot be full before it is */
+            /* the loop below starts on a 64-byte boundary: without it the bench frame's K2 moved by 0.5 % (9.33 <-> 9.38 ms) with whatever
+             * shifted the code in front of it by a few bytes - one more store in the kernel's prologue did */
+            asm volatile(".p2align 6");
             while (rem != 0u && !flush) {
                 const uint32_t ha = (uint32_t)__builtin_ctz(rem);
                 rem ^= 1u << ha;
