@@ -1191,6 +1191,7 @@ static void print_diagnostics(const DevStats& h) {
         }
         double span = (double)(h.end_max - ~h.inv_start_max) * 1e-5; /* 100 MHz ticks -> ms */
         double life = (double)h.life_sum / (double)(h.n_waves ? h.n_waves : 1) * 1e-5;
+        if (h.cont_count) fprintf(stderr, "[mirt phase timing] paths handed to the continuation launch: %u (by the late waves of the first; this split and the times below are the first launch's)\n", h.cont_count);
         fprintf(stderr, "[mirt phase timing] %llu waves, first start -> last end %.3f ms, mean wave lifetime %.3f ms (%.1f%% of the span)\n",
                 h.n_waves, span, life, 100.0 * life / (span > 0 ? span : 1));
         {
